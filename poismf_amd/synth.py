@@ -1,0 +1,55 @@
+"""Synthetic inputs for the BASELINE configs.  Host-side numpy only.
+
+C1  README example (ref: README.md:91-100): 100 x 1000, 1e4 triplets, k = 5.
+C2  uniform 1e5 x 1e5, 1e7 triplets, k = 50.
+C3  uniform 1e6 x 1e5, 1e8 triplets, k = 50.   (C4 = C3 in fp32 on 8 GPUs)
+C5  Last.FM-shaped 358 858 x 160 112, ~17 M nnz, power-law item degrees, k = 100.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def readme_coo():
+    """The reference's README data, verbatim recipe (legacy numpy RandomState seed 1)."""
+    rs = np.random.RandomState(1)  # == np.random.seed(1) followed by the module-level calls
+    nusers, nitems, nobs = 10 ** 2, 10 ** 3, 10 ** 4
+    user = rs.randint(nusers, size=nobs)
+    item = rs.randint(nitems, size=nobs)
+    count = 1 + rs.gamma(1, 1, size=nobs).astype(int)
+    return sp.coo_matrix((count.astype(np.float64), (user, item)), shape=(nusers, nitems))
+
+
+def uniform_coo(dimA, dimB, nnz, seed=1):
+    """C2-C4: uniform random positions, values 1 + floor(Gamma(1,1)); duplicates are summed later
+    by the CSR/CSC conversion exactly as SciPy does for the reference."""
+    rng = np.random.default_rng(seed)
+    row = rng.integers(0, dimA, nnz, dtype=np.int64)
+    col = rng.integers(0, dimB, nnz, dtype=np.int64)
+    val = 1.0 + np.floor(rng.gamma(1.0, 1.0, nnz))
+    return sp.coo_matrix((val, (row, col)), shape=(dimA, dimB))
+
+
+def lastfm_like_coo(nusers=358858, nitems=160112, mean_deg=47, zipf_a=0.7, seed=1):
+    """C5: per-user degree 1 + Poisson(mean_deg); items drawn from p_j ~ (j+1)^-a (duplicates within a
+    user are summed by the conversion, which slightly lowers nnz); values 1 + floor(LogNormal(4, 1.3))."""
+    rng = np.random.default_rng(seed)
+    deg = np.minimum(nitems, 1 + rng.poisson(mean_deg, nusers)).astype(np.int64)
+    nnz = int(deg.sum())
+    row = np.repeat(np.arange(nusers, dtype=np.int64), deg)
+    p = (np.arange(nitems, dtype=np.float64) + 1.0) ** (-zipf_a)
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    col = np.searchsorted(cdf, rng.random(nnz), side="right").astype(np.int64)
+    np.minimum(col, nitems - 1, out=col)
+    val = 1.0 + np.floor(rng.lognormal(4.0, 1.3, nnz))
+    return sp.coo_matrix((val, (row, col)), shape=(nusers, nitems))
+
+
+CONFIGS = {
+    # name: (builder, k, method, use_float)
+    "C1": (readme_coo, 5, "pg", True),
+    "C2": (lambda: uniform_coo(10 ** 5, 10 ** 5, 10 ** 7), 50, "pg", True),
+    "C3": (lambda: uniform_coo(10 ** 6, 10 ** 5, 10 ** 8), 50, "cg", False),
+    "C4": (lambda: uniform_coo(10 ** 6, 10 ** 5, 10 ** 8), 50, "pg", True),
+    "C5": (lastfm_like_coo, 100, "tncg", False),
+}
