@@ -1,0 +1,134 @@
+/*
+ * poismf_hip.h -- C-ABI of the MI355X (gfx950) implementation of poismf's alternating factor-update
+ * hot path.  Two shared libraries export exactly these symbols, as the reference builds its core
+ * twice (ref: setup.py:225-243, src/poismf.h:91-109):
+ *
+ *     libpoismf_hip_d.so   real_t = double
+ *     libpoismf_hip_f.so   real_t = float      (compile this header with -DUSE_FLOAT)
+ *
+ * sparse_ix is size_t (the reference's C/Python ABI, ref: src/poismf.h:76).  No torch / HIP types
+ * appear in any signature: pointers and sizes only.  All "ref:" citations are relative to the
+ * reference tree (david-cortes/poismf).
+ *
+ * There is NO CPU fallback: every entry point fails (non-zero return) if no HIP device is usable.
+ */
+#ifndef POISMF_HIP_H
+#define POISMF_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef real_t
+  #ifdef USE_FLOAT
+    #define real_t float
+  #else
+    #define real_t double
+  #endif
+#endif
+#ifndef sparse_ix
+  #define sparse_ix size_t
+#endif
+#if defined(__GNUC__) || defined(__clang__)
+  #define POISMF_HIP_API __attribute__((visibility("default")))
+#else
+  #define POISMF_HIP_API
+#endif
+
+/* ref: src/poismf.h:225  typedef enum Method {tncg = 1, cg = 2, pg = 3} Method; */
+typedef enum poismf_hip_method { POISMF_TNCG = 1, POISMF_CG = 2, POISMF_PG = 3 } poismf_hip_method;
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Drop-in entry point.
+ *
+ * Replaces: run_poismf, ref: src/poismf.h:226-233 (prototype), src/poismf.c:435-632 (body).
+ * Same name, same argument order (NOTE indptr before indices), same in-place A/B semantics, same
+ * return codes: 0 ok, 1 out of memory (host or device; also printed to stderr as the reference
+ * does, ref: src/poismf.c:501), 2 interrupted by SIGINT (ref: src/poismf.c:618-630).
+ * `method` is the reference's enum passed as int (1 tncg, 2 cg, 3 pg).
+ * `nthreads` is accepted and ignored (the row loop runs on the GPU).
+ * A, B, X* are HOST pointers owned by the caller; A and B are overwritten with the result.
+ * The device used is HIP device $POISMF_HIP_DEVICE (default 0).
+ * ------------------------------------------------------------------------------------------- */
+POISMF_HIP_API int run_poismf(
+    real_t *A, real_t *Xr, sparse_ix *Xr_indptr, sparse_ix *Xr_indices,
+    real_t *B, real_t *Xc, sparse_ix *Xc_indptr, sparse_ix *Xc_indices,
+    const size_t dimA, const size_t dimB, const size_t k,
+    const real_t l2_reg, const real_t l1_reg, const real_t w_mult, real_t step_size,
+    const int method, const bool limit_step, const size_t numiter, const size_t maxupd,
+    const bool early_stop, const bool reuse_prev,
+    const bool handle_interrupt, const int nthreads);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. Device-resident session: the same path with X, A and B kept in HBM between calls, one
+ *    half-sweep per call.  This is what bench.py times (inputs already resident) and what the
+ *    one-process-per-GPU driver uses: each rank owns a contiguous range of A rows and of B rows,
+ *    both factors are replicated, and the caller all-gathers the updated shard between halves.
+ *
+ * Replaces, per call: sum_by_cols + l1 + PG pre-scaling (ref: src/poismf.c:77-83, :512-526,
+ * :562-577) and pg_iteration / cg_iteration / tncg_iteration (ref: src/poismf.c:139-188, :275-322,
+ * :324-404) for the rows of the shard.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct poismf_hip_session poismf_hip_session;
+
+/* Creates a session on HIP device `device`.  Xr* / Xc* are HOST CSR / CSC arrays of the WHOLE matrix
+ * (size_t indices, as in run_poismf); only rows [rowA_begin,rowA_end) of the CSR and rows
+ * [rowB_begin,rowB_end) of the CSC (= columns of X) are uploaded.  Pass 0,dimA / 0,dimB for a
+ * single-GPU session.  `stream` is a hipStream_t passed as void* (NULL = the default stream); all
+ * work of this session is enqueued on it.  Returns 0, or 1 when out of memory / no device. */
+POISMF_HIP_API int poismf_hip_session_create(
+    poismf_hip_session **out, int device, void *stream,
+    const real_t *Xr, const sparse_ix *Xr_indptr, const sparse_ix *Xr_indices,
+    const real_t *Xc, const sparse_ix *Xc_indptr, const sparse_ix *Xc_indices,
+    size_t dimA, size_t dimB, size_t k,
+    size_t rowA_begin, size_t rowA_end, size_t rowB_begin, size_t rowB_end);
+
+POISMF_HIP_API void poismf_hip_session_destroy(poismf_hip_session *s);
+
+/* Device pointers to the session-owned, replicated factors: A is [dimA x k], B is [dimB x k],
+ * row-major real_t (allocations carry 16 bytes of slack because rows are gathered in 16-byte
+ * slots).  The caller may wrap them (e.g. as torch tensors) to run collectives on them. */
+POISMF_HIP_API real_t *poismf_hip_session_A(poismf_hip_session *s);
+POISMF_HIP_API real_t *poismf_hip_session_B(poismf_hip_session *s);
+
+/* Host <-> device copies of the full factors (synchronous with respect to the session stream). */
+POISMF_HIP_API int poismf_hip_session_set_factors(poismf_hip_session *s, const real_t *A_host, const real_t *B_host);
+POISMF_HIP_API int poismf_hip_session_get_factors(poismf_hip_session *s, real_t *A_host, real_t *B_host);
+
+/* Hyper-parameters of the alternation; same meaning as the run_poismf arguments. */
+typedef struct poismf_hip_params {
+    real_t l2_reg, l1_reg, w_mult, step_size;
+    int method;          /* 1 tncg, 2 cg, 3 pg */
+    int limit_step;
+    size_t maxupd;
+    int early_stop, reuse_prev;
+} poismf_hip_params;
+
+/* One half-sweep over this session's shard.  which = 0: update B rows [rowB_begin,rowB_end) against
+ * the full A (the reference's first half, ref: src/poismf.c:512-556); which = 1: update A rows against
+ * the full B (ref: src/poismf.c:562-603).  The column sums of the opposing factor are recomputed on
+ * the device from the replicated copy, so no k-vector collective is needed.  `step_size` is the step
+ * of THIS half and `cnst_div` the PG divisor (the caller keeps the reference's step schedule: cnst_div from
+ * the step before halving, A half run with the halved step -- quirk Q6; the double scaling of the column
+ * sums on the A half -- quirk Q1 -- is applied inside).  If n_unchanged != NULL (TNCG early stop) it receives
+ * the number of shard rows whose update moved by <= 1e-4 in squared norm (ref: src/poismf.c:393-396);
+ * reading it synchronises the stream.  Asynchronous otherwise.  Returns 0 or 1. */
+POISMF_HIP_API int poismf_hip_half_sweep(poismf_hip_session *s, int which, const poismf_hip_params *p,
+                          real_t step_size, real_t cnst_div, size_t *n_unchanged);
+
+/* Wall-clock (HIP events on the session stream) of the row-update kernels launched by half-sweeps
+ * since profiling was switched on: total milliseconds and number of kernel launches, per half.
+ * Synchronises the stream. */
+POISMF_HIP_API void poismf_hip_session_profile(poismf_hip_session *s, int enable);
+POISMF_HIP_API int poismf_hip_session_kernel_time(poismf_hip_session *s, int which, double *total_ms, size_t *launches);
+
+/* Number of nonzeros held by this session for half `which` (shard only). */
+POISMF_HIP_API size_t poismf_hip_session_nnz(poismf_hip_session *s, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POISMF_HIP_H */

@@ -1,0 +1,268 @@
+"""Python host side above the C-ABI (include/poismf_hip.h).
+
+Mirrors the reference's binding layer for this path:
+
+* ``_run_poismf``  -- same positional order, defaults, checks and exceptions as the Cython entry point
+  (ref: poismf/poismf_c_wrapper.pxi:57-107; note *indices before indptr* here, the reverse of the C
+  signature it forwards to);
+* ``PoisMF``       -- the fit-path subset of the reference class (ref: poismf/__init__.py:205-232
+  constructor, :336-374 ``fit``, :427-439 ``_fit``, :441-495 ``fit_unsafe``);
+* ``Session``      -- the device-resident half-sweep API used by bench.py and the multi-GPU driver.
+
+There is no CPU fallback anywhere in this module: if the HIP library cannot be loaded, or there is no
+GPU, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import harness
+
+_METHOD = {"tncg": 1, "cg": 2, "pg": 3}  # ref: src/poismf.h:225
+_LIBS = {}
+
+
+class poismf_hip_params(C.Structure):
+    pass
+
+
+def _params_type(c_real):
+    class Params(C.Structure):
+        _fields_ = [("l2_reg", c_real), ("l1_reg", c_real), ("w_mult", c_real), ("step_size", c_real),
+                    ("method", C.c_int), ("limit_step", C.c_int), ("maxupd", C.c_size_t),
+                    ("early_stop", C.c_int), ("reuse_prev", C.c_int)]
+    return Params
+
+
+# every symbol include/poismf_hip.h declares
+EXPORTED_SYMBOLS = (
+    "run_poismf", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
+    "poismf_hip_session_B", "poismf_hip_session_set_factors", "poismf_hip_session_get_factors",
+    "poismf_hip_half_sweep", "poismf_hip_session_profile", "poismf_hip_session_kernel_time",
+    "poismf_hip_session_nnz",
+)
+
+
+def load_library(use_float):
+    """dlopen libpoismf_hip_{d,f}.so (built in-tree by poismf_amd.build) and declare its prototypes."""
+    key = bool(use_float)
+    if key in _LIBS:
+        return _LIBS[key]
+    path = _build.lib_path(key)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m poismf_amd.build` "
+                           "(there is no CPU fallback for this path)")
+    lib = C.CDLL(path)
+    r = C.c_float if key else C.c_double
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    lib.run_poismf.argtypes = [vp] * 8 + [sz] * 3 + [r] * 4 + [i, C.c_bool, sz, sz] + [C.c_bool] * 3 + [i]
+    lib.run_poismf.restype = i
+    lib.poismf_hip_session_create.argtypes = [C.POINTER(vp), i, vp] + [vp] * 6 + [sz] * 3 + [sz] * 4
+    lib.poismf_hip_session_create.restype = i
+    lib.poismf_hip_session_destroy.argtypes = [vp]
+    lib.poismf_hip_session_destroy.restype = None
+    for name in ("poismf_hip_session_A", "poismf_hip_session_B"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = vp
+    for name in ("poismf_hip_session_set_factors", "poismf_hip_session_get_factors"):
+        getattr(lib, name).argtypes = [vp, vp, vp]
+        getattr(lib, name).restype = i
+    lib.params_t = _params_type(r)
+    lib.poismf_hip_half_sweep.argtypes = [vp, i, C.POINTER(lib.params_t), r, r, C.POINTER(sz)]
+    lib.poismf_hip_half_sweep.restype = i
+    lib.poismf_hip_session_profile.argtypes = [vp, i]
+    lib.poismf_hip_session_profile.restype = None
+    lib.poismf_hip_session_kernel_time.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(sz)]
+    lib.poismf_hip_session_kernel_time.restype = i
+    lib.poismf_hip_session_nnz.argtypes = [vp, i]
+    lib.poismf_hip_session_nnz.restype = sz
+    lib.real_t = r
+    _LIBS[key] = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check_arrays(use_float, reals, idx):
+    dt = np.float32 if use_float else np.float64
+    for a in reals:
+        if a.dtype != dt or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError(f"expected C-contiguous {dt.__name__} arrays")
+    for a in idx:
+        if a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError("index arrays must be C-contiguous size_t (uint64)")
+
+
+def _run_poismf(Xr, Xr_indices, Xr_indptr, Xc, Xc_indices, Xc_indptr, A, B, method="tncg", limit_step=0,
+                l2_reg=1e9, l1_reg=0, w_mult=1., step_size=1e-7, niter=10, maxupd=1, early_stop=1,
+                reuse_prev=1, handle_interrupt=1, nthreads=1):
+    """Drop-in for c_funs_{float,double}._run_poismf (ref: poismf/poismf_c_wrapper.pxi:57-107).
+    The precision is taken from A's dtype (the reference ships one module per precision)."""
+    if Xr.shape[0] == 0:
+        raise ValueError("'X' contains no non-zero entries.")                      # ref: pxi:74
+    INT_MAX = np.iinfo(C.c_int).max
+    if max(A.shape[0], A.shape[1], B.shape[0]) > INT_MAX:                           # ref: pxi:78-80
+        raise ValueError("Error: integer overflow. Dimensions cannot be larger than 2^31-1.")
+    use_float = A.dtype == np.float32
+    _check_arrays(use_float, (Xr, Xc, A, B), (Xr_indices, Xr_indptr, Xc_indices, Xc_indptr))
+    lib = load_library(use_float)
+    c_method = _METHOD.get(method, 1)                                               # ref: pxi:85-91
+    ret = lib.run_poismf(_ptr(A), _ptr(Xr), _ptr(Xr_indptr), _ptr(Xr_indices),
+                         _ptr(B), _ptr(Xc), _ptr(Xc_indptr), _ptr(Xc_indices),
+                         A.shape[0], B.shape[0], A.shape[1], l2_reg, l1_reg, w_mult, step_size, c_method,
+                         bool(limit_step), int(niter), int(maxupd), bool(early_stop), bool(reuse_prev),
+                         bool(handle_interrupt), int(nthreads))
+    if ret == 1:
+        raise MemoryError("Could not allocate enough memory.")                      # ref: pxi:104-105
+    elif ret == 2 and not handle_interrupt:
+        raise InterruptedError("Procedure was interrupted")                         # ref: pxi:106-107
+    return ret
+
+
+class PoisMF:
+    """Fit-path subset of the reference's PoisMF (ref: poismf/__init__.py:205-495).  Only what sits on
+    the factor-update path is mirrored: constructor arguments that reach run_poismf, ``fit`` for SciPy
+    COO input, ``fit_unsafe``, and the post-fit ``Bsum`` / ``Amean``."""
+
+    def __init__(self, k=50, method="tncg", l2_reg="auto", l1_reg=0.0, niter="auto", maxupd="auto",
+                 limit_step=True, initial_step=1e-7, early_stop=True, reuse_prev=False, weight_mult=1.0,
+                 random_state=1, use_float=True, handle_interrupt=True, nthreads=-1):
+        assert method in ("tncg", "cg", "pg")
+        self.k = int(k)
+        self.method = method
+        self.l2_reg_, self.maxupd_, self.niter_ = harness.auto_defaults(method, self.k, l2_reg, maxupd, niter)
+        assert self.k > 0 and self.niter_ >= 1 and self.maxupd_ >= 1
+        assert self.l2_reg_ >= 0. and l1_reg >= 0. and initial_step > 0. and weight_mult > 0.
+        self.l1_reg_ = float(l1_reg)
+        self.limit_step = bool(limit_step)
+        self.initial_step = float(initial_step)
+        self.early_stop = bool(early_stop)
+        self.reuse_prev = bool(reuse_prev)
+        self.weight_mult = float(weight_mult)
+        self.random_state = random_state
+        self.use_float = bool(use_float)
+        self.handle_interrupt = bool(handle_interrupt)
+        self.nthreads_ = 1 if nthreads < 1 else int(nthreads)
+        self.is_fitted = False
+
+    def fit(self, X):
+        csr, csc = harness.process_data(X, self.use_float)
+        self.nusers, self.nitems = X.shape
+        self.A, self.B = harness.initialize_matrices(self.nusers, self.nitems, self.k, self.use_float,
+                                                     self.random_state)
+        self._fit(csr, csc)
+        self.is_fitted = True
+        return self
+
+    def fit_unsafe(self, A, B, Xcsr, Xcsc):
+        self.A, self.B = A, B
+        self.nusers, self.nitems = A.shape[0], B.shape[0]
+        self._fit((Xcsr.data, Xcsr.indices, Xcsr.indptr), (Xcsc.data, Xcsc.indices, Xcsc.indptr))
+        self.is_fitted = True
+        return self
+
+    def _fit(self, csr, csc):                                                        # ref: __init__.py:427-439
+        _run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], self.A, self.B, self.method,
+                    self.limit_step, self.l2_reg_, self.l1_reg_, self.weight_mult, self.initial_step,
+                    self.niter_, self.maxupd_, self.early_stop, self.reuse_prev, self.handle_interrupt,
+                    self.nthreads_)
+        self.Bsum = self.B.sum(axis=0) + self.l1_reg_
+        self.Amean = self.A.mean(axis=0)
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can alias session-owned device memory."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class Session:
+    """Device-resident half-sweeps (include/poismf_hip.h section 2).  X, A and B stay in HBM; each call
+    runs one half of the alternation on this session's row shard."""
+
+    def __init__(self, csr, csc, dimA, dimB, k, use_float, device=0, stream=None, shardA=None, shardB=None):
+        self.lib = load_library(use_float)
+        self.use_float = bool(use_float)
+        self.dimA, self.dimB, self.k = int(dimA), int(dimB), int(k)
+        _check_arrays(use_float, (csr[0], csc[0]), (csr[1], csr[2], csc[1], csc[2]))
+        if len(csr[0]) == 0:
+            raise ValueError("'X' contains no non-zero entries.")
+        self.shardA = tuple(shardA) if shardA is not None else (0, self.dimA)
+        self.shardB = tuple(shardB) if shardB is not None else (0, self.dimB)
+        h = C.c_void_p()
+        rc = self.lib.poismf_hip_session_create(
+            C.byref(h), int(device), C.c_void_p(stream or 0), _ptr(csr[0]), _ptr(csr[2]), _ptr(csr[1]),
+            _ptr(csc[0]), _ptr(csc[2]), _ptr(csc[1]), self.dimA, self.dimB, self.k,
+            self.shardA[0], self.shardA[1], self.shardB[0], self.shardB[1])
+        if rc != 0 or not h.value:
+            raise MemoryError("poismf_hip_session_create failed (no usable HIP device or out of memory)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.poismf_hip_session_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def set_factors(self, A, B):
+        _check_arrays(self.use_float, (A, B), ())
+        assert A.shape == (self.dimA, self.k) and B.shape == (self.dimB, self.k)
+        if self.lib.poismf_hip_session_set_factors(self.h, _ptr(A), _ptr(B)):
+            raise RuntimeError("poismf_hip_session_set_factors failed")
+
+    def get_factors(self):
+        dt = np.float32 if self.use_float else np.float64
+        A = np.empty((self.dimA, self.k), dt)
+        B = np.empty((self.dimB, self.k), dt)
+        if self.lib.poismf_hip_session_get_factors(self.h, _ptr(A), _ptr(B)):
+            raise RuntimeError("poismf_hip_session_get_factors failed")
+        return A, B
+
+    def device_arrays(self):
+        """(A, B) as objects exposing __cuda_array_interface__ over the session's device buffers."""
+        ts = "<f4" if self.use_float else "<f8"
+        return (_DevArray(self.lib.poismf_hip_session_A(self.h), (self.dimA, self.k), ts),
+                _DevArray(self.lib.poismf_hip_session_B(self.h), (self.dimB, self.k), ts))
+
+    def make_params(self, method, l2_reg, l1_reg=0.0, w_mult=1.0, step_size=1e-7, limit_step=True, maxupd=1,
+                    early_stop=False, reuse_prev=False):
+        return self.lib.params_t(l2_reg, l1_reg, w_mult, step_size, _METHOD[method], int(limit_step), int(maxupd),
+                                 int(early_stop), int(reuse_prev))
+
+    def half_sweep(self, which, params, step_size, cnst_div, want_unchanged=False):
+        n = C.c_size_t(0)
+        rc = self.lib.poismf_hip_half_sweep(self.h, int(which), C.byref(params), step_size, cnst_div,
+                                            C.byref(n) if want_unchanged else None)
+        if rc:
+            raise RuntimeError("poismf_hip_half_sweep failed")
+        return n.value
+
+    def sweep(self, params, step_size):
+        """One full outer iteration with the reference's schedule (ref: src/poismf.c:506-608): B half, then
+        (PG) halve the step, then A half.  Returns the step for the next iteration."""
+        l2 = float(params.l2_reg)
+        cnst_div = 1. / (1. + 2. * l2 * step_size)
+        self.half_sweep(0, params, step_size, cnst_div)
+        if params.method == _METHOD["pg"]:
+            step_size *= 0.5
+        self.half_sweep(1, params, step_size, cnst_div)
+        return step_size
+
+    def profile(self, enable=True):
+        self.lib.poismf_hip_session_profile(self.h, int(enable))
+
+    def kernel_time(self, which):
+        ms, n = C.c_double(0), C.c_size_t(0)
+        if self.lib.poismf_hip_session_kernel_time(self.h, int(which), C.byref(ms), C.byref(n)):
+            raise RuntimeError("poismf_hip_session_kernel_time failed")
+        return ms.value, n.value
+
+    def nnz(self, which):
+        return self.lib.poismf_hip_session_nnz(self.h, int(which))

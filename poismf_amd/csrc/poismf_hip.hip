@@ -1,0 +1,587 @@
+// poismf_hip.hip -- kernels and host side of the MI355X implementation of poismf's alternating
+// factor-update path.  Compiled twice (real_t = double, and float with -DUSE_FLOAT) into
+// libpoismf_hip_d.so / libpoismf_hip_f.so; the C-ABI is declared in include/poismf_hip.h.
+//
+// Host (this file, plain C++): the outer A/B alternation, step schedule, early-stop logic, SIGINT
+// plumbing and return codes of run_poismf (ref: src/poismf.c:435-632), plus a device-resident
+// session used by bench.py and by the one-process-per-GPU driver.
+// Device: one launch per (half-sweep, row bin); one wavefront per row (row_eval.hpp, solvers.hpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/poismf_hip.h"
+#include "solvers.hpp"
+
+using namespace pmf;
+
+// =================================================================================================
+// Kernels
+// =================================================================================================
+template <class T> struct HalfArgs {
+    T* M;                             // factor being updated, [dimM x k]
+    const T* F;                       // opposing factor, [dimF x k] (+16 B of slack)
+    const unsigned long long* indptr; // shard-local CSR row pointers (nrows_local + 1)
+    const unsigned* indices;
+    const T* values;
+    const unsigned* perm;             // shard-local row ids, sorted by nnz descending
+    unsigned perm_begin, nrows;       // this launch covers perm[perm_begin, perm_begin + nrows)
+    unsigned row_offset;              // first global row of the shard (M row = row_offset + local id)
+    const T* bsum;                    // k-vector: colsum(F) + l1 (pre-scaled for PG when w == 1)
+    TileGeom geom;
+    RowParams<T> P;
+    int reuse_prev, early_stop;
+    unsigned* n_unchanged;
+};
+
+enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
+
+// One wavefront (= one 64-thread workgroup, so no workgroup barrier is ever needed and the LDS tile
+// is private) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the nnz-sorted permutation.
+template <class T, int NC, int METHOD>
+__global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    RowEval<T, NC> ev;
+    ev.init(a.geom, a.F, smem);
+    const int k = a.geom.k;
+    T bs[NC];
+    ev.load_vec(a.bsum, bs);
+
+    for (unsigned r = blockIdx.x; r < a.nrows; r += gridDim.x) {
+        const unsigned lrow = uniform(a.perm[a.perm_begin + r]);
+        const unsigned long long p0 = a.indptr[lrow], p1 = a.indptr[lrow + 1];
+        const unsigned nnz = uniform((unsigned)(p1 - p0));
+        T* out = a.M + (size_t)(a.row_offset + lrow) * (size_t)k;
+        T x[NC];
+        if (nnz == 0) {  // rows without data are forced to zero every half (quirk Q7)
+            PMF_EW x[i] = (T)0;
+            ev.store_vec(out, x);
+            continue;
+        }
+        ev.begin_row(a.indices + p0, a.values + p0, nnz);
+        ev.load_vec(out, x);
+
+        // per-row constant term: the k-vector itself, or (w != 1) the reference's Bsum_w row
+        //   (w - 1) sum_j F_j + Bsum          ref: src/poismf.c:85-123 (adjustment_Bsum)
+        T shift[NC];
+        PMF_EW shift[i] = bs[i];
+        const bool weighted = a.P.w != (T)1;
+        if (weighted) {
+            T cs[NC];
+            PMF_EW cs[i] = (T)0;
+            ev.tile_colsum(cs);
+            const T wm1 = a.P.w - (T)1.;
+            PMF_EW {
+                shift[i] = cs[i] * wm1;
+                shift[i] = shift[i] + bs[i];
+            }
+            if (METHOD == K_PG) { PMF_EW shift[i] = shift[i] * a.P.neg_step; }  // dscal_large, ref: :526, :576
+        }
+
+        if constexpr (METHOD == K_PG) {
+            pg_row(ev, a.P, x, shift);
+        } else if constexpr (METHOD == K_CG) {
+            cg_row(ev, a.P, shift, x, weighted);
+        } else {
+            T prev[NC];
+            PMF_EW prev[i] = x[i];
+            if (!a.reuse_prev) { PMF_EW x[i] = (T)1e-3; }                   // ref: src/poismf.c:379-381
+            (void)Tnc<T, NC>::minimize(ev, a.P, shift, x);
+            if (a.early_stop) {                                             // ref: src/poismf.c:393-396
+                PMF_EW prev[i] = prev[i] - x[i];
+                const T moved = ev.dot(prev, prev);
+                if ((double)moved <= 1e-4 && ev.lane == 0) atomicAdd(a.n_unchanged, 1u);
+            }
+        }
+        ev.store_vec(out, x);
+    }
+}
+
+// ---- column sums of a dense [n x k] factor: sum_by_cols, ref: src/poismf.c:77-83 ---------------------
+// stage 1: wave w accumulates rows w, w + nw, ...; stage 2: one wave adds the nw partials in order,
+// then applies `+ l1` (ref: :513-514) and the PG pre-scalings (ref: :523-526, :573-577, quirk Q1).
+template <class T, int NC>
+__global__ __launch_bounds__(WAVE) void colsum_partial_kernel(const T* M, size_t n, int k, T* partial)
+{
+    const int lane = lane_id();
+    T acc[NC];
+    PMF_EW acc[i] = (T)0;
+    for (size_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const T* row = M + r * (size_t)k;
+        PMF_EW if (lane + WAVE * i < k) acc[i] += row[lane + WAVE * i];
+    }
+    PMF_EW if (lane + WAVE * i < k) partial[(size_t)blockIdx.x * k + lane + WAVE * i] = acc[i];
+}
+template <class T, int NC>
+__global__ __launch_bounds__(WAVE) void colsum_final_kernel(const T* partial, int nw, int k, T l1, T scale,
+                                                            int nscale, T* out)
+{
+    const int lane = lane_id();
+    PMF_EW {
+        const int c = lane + WAVE * i;
+        if (c < k) {
+            T s = (T)0;
+            for (int w = 0; w < nw; w++) s += partial[(size_t)w * k + c];
+            if (l1 > (T)0.) s += l1;
+            for (int q = 0; q < nscale; q++) s *= scale;
+            out[c] = s;
+        }
+    }
+}
+
+// =================================================================================================
+// Host side
+// =================================================================================================
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "poismf_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));          \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+
+constexpr size_t LDS_PER_CU = 160 * 1024;
+constexpr size_t LDS_RESIDENT_LIMIT = 64 * 1024;  // largest tile a single wave may claim
+constexpr int NUM_CU = 256;
+
+struct Bin {
+    unsigned begin, count;  // range of the nnz-sorted permutation
+    unsigned max_nnz;
+};
+
+struct Half {
+    size_t dimM = 0, dimF = 0;
+    size_t row_begin = 0, row_end = 0;  // shard
+    size_t nnz = 0;
+    unsigned long long* d_indptr = nullptr;
+    unsigned* d_indices = nullptr;
+    real_t* d_values = nullptr;
+    unsigned* d_perm = nullptr;
+    std::vector<Bin> bins;
+};
+
+struct ProfRec { hipEvent_t t0, t1; int which; };
+
+}  // namespace
+
+struct poismf_hip_session {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t dimA = 0, dimB = 0, k = 0;
+    real_t *dA = nullptr, *dB = nullptr;
+    Half half[2];  // [0]: rows of B (CSC), [1]: rows of A (CSR)
+    real_t* d_bsum = nullptr;
+    real_t* d_partial = nullptr;
+    unsigned* d_counter = nullptr;
+    int colsum_waves = 2048;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+};
+
+namespace {
+
+void free_half(Half& h)
+{
+    if (h.d_indptr) (void)hipFree(h.d_indptr);
+    if (h.d_indices) (void)hipFree(h.d_indices);
+    if (h.d_values) (void)hipFree(h.d_values);
+    if (h.d_perm) (void)hipFree(h.d_perm);
+    h = Half();
+}
+
+// Upload rows [r0, r1) of a host CSR (size_t indices) with shard-local pointers and u32 indices; build
+// the nnz-descending permutation and its power-of-two bins.
+int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* indptr, const sparse_ix* indices,
+               size_t dimM, size_t dimF, size_t r0, size_t r1)
+{
+    h.dimM = dimM; h.dimF = dimF; h.row_begin = r0; h.row_end = r1;
+    const size_t nloc = r1 - r0;
+    const size_t base = indptr[r0];
+    h.nnz = indptr[r1] - base;
+    std::vector<unsigned long long> lptr(nloc + 1);
+    for (size_t i = 0; i <= nloc; i++) lptr[i] = (unsigned long long)(indptr[r0 + i] - base);
+    std::vector<unsigned> lidx(h.nnz ? h.nnz : 1);
+    for (size_t i = 0; i < h.nnz; i++) lidx[i] = (unsigned)indices[base + i];
+
+    // counting sort of rows by nnz, descending (stable: ties keep row order)
+    std::vector<unsigned> perm(nloc ? nloc : 1);
+    {
+        std::vector<std::pair<unsigned, unsigned>> key(nloc);
+        for (size_t i = 0; i < nloc; i++) key[i] = { (unsigned)(lptr[i + 1] - lptr[i]), (unsigned)i };
+        std::stable_sort(key.begin(), key.end(),
+                         [](const std::pair<unsigned, unsigned>& a, const std::pair<unsigned, unsigned>& b) { return a.first > b.first; });
+        h.bins.clear();
+        for (size_t i = 0; i < nloc; i++) {
+            perm[i] = key[i].second;
+            const unsigned n = key[i].first;
+            unsigned cls = 16;
+            while (cls < n) cls <<= 1;  // bins: <=16, <=32, <=64, ...
+            if (h.bins.empty() || cls != h.bins.back().max_nnz) h.bins.push_back({ (unsigned)i, 0u, cls });
+            h.bins.back().count++;
+        }
+        // record the true maximum of each bin (first row, since sorted)
+        for (auto& b : h.bins) b.max_nnz = key[b.begin].first;
+    }
+    HIP_TRY(hipMalloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1)));
+    HIP_TRY(hipMalloc(&h.d_indices, sizeof(unsigned) * (h.nnz ? h.nnz : 1)));
+    HIP_TRY(hipMalloc(&h.d_values, sizeof(real_t) * (h.nnz ? h.nnz : 1)));
+    HIP_TRY(hipMalloc(&h.d_perm, sizeof(unsigned) * (nloc ? nloc : 1)));
+    HIP_TRY(hipMemcpyAsync(h.d_indptr, lptr.data(), sizeof(unsigned long long) * (nloc + 1), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h.d_indices, lidx.data(), sizeof(unsigned) * h.nnz, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h.d_values, val + base, sizeof(real_t) * h.nnz, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(h.d_perm, perm.data(), sizeof(unsigned) * nloc, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // host staging vectors die here
+    return 0;
+}
+
+TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass)
+{
+    TileGeom g;
+    g.k = (int)k;
+    g.s_load = (int)((k * sizeof(real_t) + 15) / 16);
+    g.s_stride = g.s_load | 1;
+    // tile capacity: whole rows of this bin if that fits the per-wave budget, else stream in chunks.
+    // A single-pass solver (PG with one update) gains nothing from residency: keep tiles small there
+    // so that many waves per CU keep gathers in flight.
+    const unsigned want = std::max(16u, bin_max_nnz);
+    const unsigned stream_chunk = 128;
+    unsigned cap = want;
+    g.resident = 1;
+    TileGeom probe = g;
+    probe.cap = (int)cap;
+    if (lds_bytes_per_wave(probe, sizeof(real_t)) > LDS_RESIDENT_LIMIT || (single_pass && cap > stream_chunk)) {
+        cap = stream_chunk;
+        probe.cap = (int)cap;
+        while (cap > 16 && lds_bytes_per_wave(probe, sizeof(real_t)) > LDS_RESIDENT_LIMIT) { cap /= 2; probe.cap = (int)cap; }
+        g.resident = 0;
+    }
+    g.cap = (int)cap;
+    return g;
+}
+
+template <int NC, int METHOD> int launch_bin(poismf_hip_session* s, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+{
+    auto kern = half_sweep_kernel<real_t, NC, METHOD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)LDS_PER_CU));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NC> int launch_method(poismf_hip_session* s, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+{
+    switch (method) {
+        case POISMF_PG: return launch_bin<NC, K_PG>(s, a, lds, grid);
+        case POISMF_CG: return launch_bin<NC, K_CG>(s, a, lds, grid);
+        default: return launch_bin<NC, K_TNCG>(s, a, lds, grid);
+    }
+}
+
+int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 0)); }
+
+template <int NC> int launch_colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
+{
+    const int nw = (int)std::min<size_t>((size_t)s->colsum_waves, std::max<size_t>(n, 1));
+    hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(nw), dim3(WAVE), 0, s->stream, M, n, (int)s->k, s->d_partial);
+    hipLaunchKernelGGL((colsum_final_kernel<real_t, NC>), dim3(1), dim3(WAVE), 0, s->stream, s->d_partial, nw, (int)s->k, l1,
+                       scale, nscale, s->d_bsum);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
+{
+    switch (nc_for_k(s->k)) {
+        case 1: return launch_colsum<1>(s, M, n, l1, scale, nscale);
+        case 2: return launch_colsum<2>(s, M, n, l1, scale, nscale);
+        case 4: return launch_colsum<4>(s, M, n, l1, scale, nscale);
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream, const real_t* Xr,
+                              const sparse_ix* Xr_indptr, const sparse_ix* Xr_indices, const real_t* Xc,
+                              const sparse_ix* Xc_indptr, const sparse_ix* Xc_indices, size_t dimA, size_t dimB, size_t k,
+                              size_t rowA_begin, size_t rowA_end, size_t rowB_begin, size_t rowB_end)
+{
+    *out = nullptr;
+    if (nc_for_k(k) == 0 || k == 0) {
+        fprintf(stderr, "poismf_hip: k = %zu is outside the supported range 1..256\n", k);
+        return 1;
+    }
+    if (rowA_end > dimA || rowB_end > dimB || rowA_begin > rowA_end || rowB_begin > rowB_end) return 1;
+    HIP_TRY(hipSetDevice(device));
+    poismf_hip_session* s = new (std::nothrow) poismf_hip_session();
+    if (!s) return 1;
+    s->device = device;
+    s->stream = (hipStream_t)stream;
+    s->dimA = dimA; s->dimB = dimB; s->k = k;
+    auto fail = [&]() { poismf_hip_session_destroy(s); return 1; };
+    const size_t slack = 16;
+    if (hipMalloc(&s->dA, dimA * k * sizeof(real_t) + slack) != hipSuccess) return fail();
+    if (hipMalloc(&s->dB, dimB * k * sizeof(real_t) + slack) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->dA, 0, dimA * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->dB, 0, dimB * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_bsum, k * sizeof(real_t)) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t)) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_counter, sizeof(unsigned)) != hipSuccess) return fail();
+    // half 0 updates B: rows of the CSC; half 1 updates A: rows of the CSR
+    if (build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, rowB_begin, rowB_end)) return fail();
+    if (build_half(s->half[1], s->stream, Xr, Xr_indptr, Xr_indices, dimA, dimB, rowA_begin, rowA_end)) return fail();
+    *out = s;
+    return 0;
+}
+
+void poismf_hip_session_destroy(poismf_hip_session* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
+    free_half(s->half[0]);
+    free_half(s->half[1]);
+    if (s->dA) (void)hipFree(s->dA);
+    if (s->dB) (void)hipFree(s->dB);
+    if (s->d_bsum) (void)hipFree(s->d_bsum);
+    if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->d_counter) (void)hipFree(s->d_counter);
+    delete s;
+}
+
+real_t* poismf_hip_session_A(poismf_hip_session* s) { return s->dA; }
+real_t* poismf_hip_session_B(poismf_hip_session* s) { return s->dB; }
+size_t poismf_hip_session_nnz(poismf_hip_session* s, int which) { return s->half[which ? 1 : 0].nnz; }
+
+int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, const real_t* B_host)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(s->dA, A_host, s->dimA * s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->dB, B_host, s->dimB * s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int poismf_hip_session_get_factors(poismf_hip_session* s, real_t* A_host, real_t* B_host)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(A_host, s->dA, s->dimA * s->k * sizeof(real_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(B_host, s->dB, s->dimB * s->k * sizeof(real_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+void poismf_hip_session_profile(poismf_hip_session* s, int enable)
+{
+    (void)hipStreamSynchronize(s->stream);
+    for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
+    s->prof.clear();
+    s->profiling = enable != 0;
+}
+
+int poismf_hip_session_kernel_time(poismf_hip_session* s, int which, double* total_ms, size_t* launches)
+{
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    double tot = 0;
+    size_t n = 0;
+    for (auto& p : s->prof) {
+        if (p.which != which) continue;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.t0, p.t1));
+        tot += ms;
+        n++;
+    }
+    *total_ms = tot;
+    *launches = n;
+    return 0;
+}
+
+int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_params* p, real_t step_size, real_t cnst_div,
+                          size_t* n_unchanged)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    which = which ? 1 : 0;
+    Half& h = s->half[which];
+    real_t* M = which ? s->dA : s->dB;
+    const real_t* F = which ? s->dB : s->dA;
+    const size_t dimF = which ? s->dimB : s->dimA;
+    const bool is_pg = p->method == POISMF_PG;
+    const bool weighted = p->w_mult != (real_t)1.;
+
+    // column sums of the fixed factor (+ l1), with the PG pre-scaling when w == 1:
+    //   B half: * (-step)            ref: src/poismf.c:523-524
+    //   A half: * (-step) twice      ref: src/poismf.c:573-577 (quirk Q1)
+    const real_t neg_step = -step_size;
+    int nscale = 0;
+    if (is_pg && !weighted) nscale = which ? 2 : 1;
+    if (colsum(s, F, dimF, p->l1_reg, neg_step, nscale)) return 1;
+
+    HalfArgs<real_t> a;
+    a.M = M; a.F = F;
+    a.indptr = h.d_indptr; a.indices = h.d_indices; a.values = h.d_values; a.perm = h.d_perm;
+    a.row_offset = (unsigned)h.row_begin;
+    a.bsum = s->d_bsum;
+    a.P.l2 = p->l2_reg; a.P.w = p->w_mult;
+    a.P.step = step_size * p->w_mult;  // ref: src/poismf.c:151
+    a.P.cnst_div = cnst_div;
+    a.P.neg_step = neg_step;
+    a.P.maxupd = (int)std::min<size_t>(p->maxupd, 0x7fffffff);
+    a.P.limit_step = p->limit_step;
+    a.P.max_cg_it = (int)std::max(1.0, std::min(50.0, (double)(real_t)s->k / 2.0));  // ref: src/poismf.c:342
+    a.reuse_prev = p->reuse_prev;
+    a.early_stop = (p->method == POISMF_TNCG) && p->early_stop && n_unchanged != nullptr;
+    a.n_unchanged = s->d_counter;
+    if (a.early_stop) HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned), s->stream));
+
+    const bool single_pass = is_pg && p->maxupd <= 1 && !weighted;
+    ProfRec rec{};
+    if (s->profiling) {
+        HIP_TRY(hipEventCreate(&rec.t0));
+        HIP_TRY(hipEventCreate(&rec.t1));
+        rec.which = which;
+        HIP_TRY(hipEventRecord(rec.t0, s->stream));
+    }
+    for (const Bin& b : h.bins) {
+        a.perm_begin = b.begin;
+        a.nrows = b.count;
+        a.geom = plan_geom(s->k, b.max_nnz, single_pass);
+        const size_t lds = lds_bytes_per_wave(a.geom, sizeof(real_t));
+        const unsigned waves_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / lds));
+        const unsigned grid = (unsigned)std::min<size_t>(b.count, (size_t)NUM_CU * waves_per_cu * 2);
+        int rc = 1;
+        switch (nc_for_k(s->k)) {
+            case 1: rc = launch_method<1>(s, p->method, a, lds, grid); break;
+            case 2: rc = launch_method<2>(s, p->method, a, lds, grid); break;
+            case 4: rc = launch_method<4>(s, p->method, a, lds, grid); break;
+        }
+        if (rc) return 1;
+    }
+    if (s->profiling) {
+        HIP_TRY(hipEventRecord(rec.t1, s->stream));
+        s->prof.push_back(rec);
+    }
+    if (a.early_stop) {
+        unsigned cnt = 0;
+        HIP_TRY(hipMemcpyAsync(&cnt, s->d_counter, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        *n_unchanged = cnt;
+    }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// run_poismf: the drop-in                                   ref: src/poismf.c:435-632
+// -------------------------------------------------------------------------------------------------
+static volatile sig_atomic_t g_should_stop = 0;
+static bool g_handle_locked = false;
+static std::mutex g_handle_mutex;
+static void on_sigint(int)
+{
+    g_should_stop = 1;  // the reference also prints here; fprintf is not async-signal-safe, so run_poismf reports it
+}
+
+int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indices, real_t* B, real_t* Xc,
+               sparse_ix* Xc_indptr, sparse_ix* Xc_indices, const size_t dimA, const size_t dimB, const size_t k,
+               const real_t l2_reg, const real_t l1_reg, const real_t w_mult, real_t step_size, const int method,
+               const bool limit_step, const size_t numiter, const size_t maxupd, const bool early_stop,
+               const bool reuse_prev, const bool handle_interrupt, const int nthreads)
+{
+    (void)nthreads;
+    typedef void (*sig_fn)(int);
+    sig_fn old_handler = nullptr;
+    bool has_lock = false;
+    {
+        std::lock_guard<std::mutex> lk(g_handle_mutex);  // ref: :446-455
+        if (!g_handle_locked) {
+            g_handle_locked = true;
+            has_lock = true;
+            g_should_stop = 0;
+            old_handler = signal(SIGINT, on_sigint);
+        }
+    }
+
+    int ret_code = 0;
+    poismf_hip_session* s = nullptr;
+    int device = 0;
+    if (const char* e = getenv("POISMF_HIP_DEVICE")) device = atoi(e);
+
+    if (poismf_hip_session_create(&s, device, nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k, 0,
+                                  dimA, 0, dimB) ||
+        poismf_hip_session_set_factors(s, A, B)) {
+        fprintf(stderr, "Error: out of memory.\n");  // ref: :501
+        ret_code = 1;
+    } else {
+        poismf_hip_params p;
+        p.l2_reg = l2_reg; p.l1_reg = l1_reg; p.w_mult = w_mult; p.step_size = step_size;
+        p.method = method; p.limit_step = limit_step; p.maxupd = maxupd;
+        p.early_stop = early_stop; p.reuse_prev = reuse_prev;
+        const bool tn_stop = (method == POISMF_TNCG) && early_stop;
+        bool stopped_earlyA = false, stopped_earlyB = false;
+        bool failed = false;
+
+        for (size_t it = 0; it < numiter && !failed; it++) {
+            if (g_should_stop) break;
+            // quirk Q6: the divisor uses the step before halving and is reused by the A half
+            const real_t cnst_div = 1. / (1. + 2. * l2_reg * step_size);
+
+            // ---- B half first (quirk Q5) ----
+            if (!(method == POISMF_TNCG && stopped_earlyB)) {
+                size_t unchanged = 0;
+                if (poismf_hip_half_sweep(s, 0, &p, step_size, cnst_div, tn_stop ? &unchanged : nullptr)) { failed = true; break; }
+                if (tn_stop) stopped_earlyB = ((double)unchanged / (double)dimB) >= .95;  // ref: :401-403 (quirk Q7)
+            }
+            if (method == POISMF_PG) step_size *= 0.5;  // ref: :532-533
+            if (hipStreamSynchronize(s->stream) != hipSuccess) { failed = true; break; }
+            if (g_should_stop) break;
+
+            // ---- A half ----
+            if (!(method == POISMF_TNCG && stopped_earlyA)) {
+                size_t unchanged = 0;
+                if (poismf_hip_half_sweep(s, 1, &p, step_size, cnst_div, tn_stop ? &unchanged : nullptr)) { failed = true; break; }
+                if (tn_stop) stopped_earlyA = ((double)unchanged / (double)dimA) >= .95;
+            }
+            if (hipStreamSynchronize(s->stream) != hipSuccess) { failed = true; break; }
+            if (stopped_earlyA && stopped_earlyB) break;
+        }
+        if (failed || poismf_hip_session_get_factors(s, A, B)) {
+            fprintf(stderr, "Error: out of memory.\n");
+            ret_code = 1;
+        }
+    }
+    poismf_hip_session_destroy(s);
+
+    {
+        std::lock_guard<std::mutex> lk(g_handle_mutex);  // ref: :618-630
+        const bool stopped = g_should_stop != 0;
+        if (stopped) fprintf(stderr, "Error: procedure was interrupted\n");
+        if (stopped && ret_code != 1) ret_code = 2;
+        if (has_lock) {
+            signal(SIGINT, old_handler);
+            g_handle_locked = false;
+            g_should_stop = 0;
+        }
+        if (stopped && !handle_interrupt) raise(SIGINT);
+    }
+    return ret_code;
+}
+
+}  // extern "C"

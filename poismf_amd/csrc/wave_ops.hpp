@@ -1,0 +1,113 @@
+// wave_ops.hpp -- 64-lane wavefront primitives for gfx950 (CDNA4).
+//
+// Every row sub-problem is owned by ONE wavefront, so all solver scalars are wave-uniform and every
+// k-length reduction is a cross-lane reduction: 4 DPP steps inside each 16-lane row (v_add_*_dpp,
+// no LDS traffic), then 4 v_readlane + 3 adds across the rows.  Results are returned through
+// readfirstlane so the compiler knows they are uniform (scalar branches, SGPR operands).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pmf {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+
+// ---- raw lane movement on 32- and 64-bit payloads -------------------------------------------
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)dpp_i32<CTRL>((int)(unsigned)b);
+    const unsigned hi = (unsigned)dpp_i32<CTRL>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return dpp_i32<CTRL>(v); }
+
+__device__ __forceinline__ float read_lane(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double read_lane(double v, int l)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int read_lane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+__device__ __forceinline__ float uniform(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double uniform(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ bool uniform(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+
+// ---- reductions ---------------------------------------------------------------------------------
+struct OpSum { template <class T> static __device__ __forceinline__ T f(T a, T b) { return a + b; } };
+struct OpMin {
+    static __device__ __forceinline__ float f(float a, float b) { return fminf(a, b); }
+    static __device__ __forceinline__ double f(double a, double b) { return fmin(a, b); }
+    static __device__ __forceinline__ int f(int a, int b) { return a < b ? a : b; }
+};
+struct OpMax {
+    static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ double f(double a, double b) { return fmax(a, b); }
+    static __device__ __forceinline__ int f(int a, int b) { return a > b ? a : b; }
+};
+
+// DPP controls: quad_perm[1,0,3,2] = 0xB1, quad_perm[2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140.  After the four steps every lane of a 16-lane row holds that row's result.
+template <class Op, class T> __device__ __forceinline__ T wave_reduce(T x)
+{
+    x = Op::f(x, dpp_mov<0xB1>(x));
+    x = Op::f(x, dpp_mov<0x4E>(x));
+    x = Op::f(x, dpp_mov<0x141>(x));
+    x = Op::f(x, dpp_mov<0x140>(x));
+    const T r0 = read_lane(x, 0), r1 = read_lane(x, 16), r2 = read_lane(x, 32), r3 = read_lane(x, 48);
+    return uniform(Op::f(Op::f(r0, r1), Op::f(r2, r3)));
+}
+template <class T> __device__ __forceinline__ T wave_sum(T x) { return wave_reduce<OpSum>(x); }
+template <class T> __device__ __forceinline__ T wave_min(T x) { return wave_reduce<OpMin>(x); }
+template <class T> __device__ __forceinline__ T wave_max(T x) { return wave_reduce<OpMax>(x); }
+
+// Orders this wave's LDS traffic: data written by some lanes is read by other lanes of the SAME wave.
+// The hardware executes one wave's DS instructions in issue order; this keeps the compiler from
+// reordering them and is free at run time.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Double-typed libm wrappers.  The reference's C sources call fabs/sqrt/log/log10/fmin/fmax, which in
+// C are the DOUBLE functions even in its float build (USE_FLOAT); C++ overload resolution would pick
+// the float overloads and change the rounding of the surrounding expressions.
+__device__ __forceinline__ double d_abs(double v) { return fabs(v); }
+__device__ __forceinline__ double d_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ double d_log(double v) { return log(v); }
+__device__ __forceinline__ double d_log10(double v) { return log10(v); }
+__device__ __forceinline__ double d_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double d_max(double a, double b) { return fmax(a, b); }
+
+template <class T> struct Eps;
+template <> struct Eps<float> { static constexpr float v = 1.1920928955078125e-07f; };   // FLT_EPSILON
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };   // DBL_EPSILON
+
+}  // namespace pmf
