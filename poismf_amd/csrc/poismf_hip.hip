@@ -120,19 +120,33 @@ __global__ __launch_bounds__(WAVE) void colsum_partial_kernel(const T* M, size_t
     }
     PMF_EW if (lane + WAVE * i < k) partial[(size_t)blockIdx.x * k + lane + WAVE * i] = acc[i];
 }
+// stage 2: 16 waves; wave w adds partials w, w + 16, ... in order, then wave 0 adds the 16 wave totals in order
+// (fixed summation order => bit-reproducible), applies `+ l1` and the PG pre-scalings.
+constexpr int COLSUM_FINAL_WAVES = 16;
 template <class T, int NC>
-__global__ __launch_bounds__(WAVE) void colsum_final_kernel(const T* partial, int nw, int k, T l1, T scale,
-                                                            int nscale, T* out)
+__global__ __launch_bounds__(WAVE* COLSUM_FINAL_WAVES) void colsum_final_kernel(const T* partial, int nw, int k, T l1, T scale,
+                                                                                 int nscale, T* out)
 {
+    __shared__ T part[COLSUM_FINAL_WAVES][NC * WAVE];
     const int lane = lane_id();
-    PMF_EW {
-        const int c = lane + WAVE * i;
-        if (c < k) {
-            T s = (T)0;
-            for (int w = 0; w < nw; w++) s += partial[(size_t)w * k + c];
-            if (l1 > (T)0.) s += l1;
-            for (int q = 0; q < nscale; q++) s *= scale;
-            out[c] = s;
+    const int w = (int)(threadIdx.x / WAVE);
+    T acc[NC];
+    PMF_EW acc[i] = (T)0;
+    for (int r = w; r < nw; r += COLSUM_FINAL_WAVES) {
+        PMF_EW if (lane + WAVE * i < k) acc[i] += partial[(size_t)r * k + lane + WAVE * i];
+    }
+    PMF_EW part[w][lane + WAVE * i] = acc[i];
+    __syncthreads();
+    if (w == 0) {
+        PMF_EW {
+            const int c = lane + WAVE * i;
+            if (c < k) {
+                T s = part[0][c];
+                for (int q = 1; q < COLSUM_FINAL_WAVES; q++) s += part[q][c];
+                if (l1 > (T)0.) s += l1;
+                for (int q = 0; q < nscale; q++) s *= scale;
+                out[c] = s;
+            }
         }
     }
 }
@@ -299,7 +313,7 @@ template <int NC> int launch_colsum(poismf_hip_session* s, const real_t* M, size
 {
     const int nw = (int)std::min<size_t>((size_t)s->colsum_waves, std::max<size_t>(n, 1));
     hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(nw), dim3(WAVE), 0, s->stream, M, n, (int)s->k, s->d_partial);
-    hipLaunchKernelGGL((colsum_final_kernel<real_t, NC>), dim3(1), dim3(WAVE), 0, s->stream, s->d_partial, nw, (int)s->k, l1,
+    hipLaunchKernelGGL((colsum_final_kernel<real_t, NC>), dim3(1), dim3(WAVE * COLSUM_FINAL_WAVES), 0, s->stream, s->d_partial, nw, (int)s->k, l1,
                        scale, nscale, s->d_bsum);
     HIP_TRY(hipGetLastError());
     return 0;

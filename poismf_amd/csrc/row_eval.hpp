@@ -97,6 +97,35 @@ template <class T, int NC> struct RowEval {
         wave_lds_fence();
     }
 
+    // One batch of the gather: UU x 64 consecutive 16-byte slots starting at slot q0.  All UU global loads
+    // are issued back to back (nothing consumes a result before the last one is in flight), then masked and
+    // written to the tile.  Lanes past the end of the chunk load slot (0,0) again (an L1 hit) and store nothing.
+    template <int UU> __device__ __forceinline__ void gather_batch(int q0, int Q, int& j, int& t)
+    {
+        SU v[UU];
+        int dst[UU];
+        bool last[UU];
+#pragma unroll
+        for (int u = 0; u < UU; u++) {
+            const bool ok = q0 + u * WAVE + lane < Q;
+            const int jr = ok ? j : 0, tr = ok ? t : 0;
+            dst[u] = ok ? jr * s_stride + tr : -1;
+            last[u] = tr == s_load - 1;
+            const unsigned col = idxb[jr];
+            v[u] = *(const SU*)(F + (size_t)col * (size_t)k + (size_t)(tr * SN));
+            t += gdt; j += gdj;
+            if (t >= s_load) { t -= s_load; j += 1; }
+        }
+#pragma unroll
+        for (int u = 0; u < UU; u++) {
+            SA w;
+#pragma unroll
+            for (int e = 0; e < SN; e++)  // the last slot of a factor row reads past its end: zero the excess
+                w.v[e] = (e >= 1 && last[u] && e >= tail) ? (T)0 : v[u].v[e];
+            if (dst[u] >= 0) tile[dst[u]] = w;
+        }
+    }
+
     // Gather chunk [c0, c0+cn) of the current row: indices and values, then the factor rows.
     __device__ __forceinline__ void load_chunk(unsigned c0, int cn)
     {
@@ -107,37 +136,13 @@ template <class T, int NC> struct RowEval {
         wave_lds_fence();
         const int Q = cn * s_load;  // 16-byte slots to fetch
         int j = gj0, t = gt0;
-        constexpr int U = 8;        // loads kept in flight per lane (8 x 16 B x 64 lanes = 8 KiB per wave)
-        for (int q0 = 0; q0 < Q; q0 += WAVE * U) {
-            SU v[U];
-            int dst[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                dst[u] = -1;
-                if (q0 + u * WAVE < Q) {  // wave-uniform
-                    const bool ok = q0 + u * WAVE + lane < Q;
-                    const int jr = ok ? j : 0, tr = ok ? t : 0;
-                    const unsigned col = idxb[jr];
-                    v[u] = *(const SU*)(F + (size_t)col * (size_t)k + (size_t)(tr * SN));
-                    if (tail != SN && tr == s_load - 1) {  // last slot reads past the row: zero the excess
-#pragma unroll
-                        for (int e = 1; e < SN; e++) if (e >= tail) v[u].v[e] = (T)0;
-                    }
-                    dst[u] = ok ? jr * s_stride + tr : -1;
-                    t += gdt; j += gdj;
-                    if (t >= s_load) { t -= s_load; j += 1; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (dst[u] >= 0) {
-                    SA w;
-#pragma unroll
-                    for (int e = 0; e < SN; e++) w.v[e] = v[u].v[e];
-                    tile[dst[u]] = w;
-                }
-            }
-        }
+        int q0 = 0;
+        for (; q0 + 8 * WAVE <= Q; q0 += 8 * WAVE) gather_batch<8>(q0, Q, j, t);  // 8 KiB in flight per wave
+        const int rem = Q - q0;
+        if (rem > 4 * WAVE) gather_batch<8>(q0, Q, j, t);
+        else if (rem > 2 * WAVE) gather_batch<4>(q0, Q, j, t);
+        else if (rem > WAVE) gather_batch<2>(q0, Q, j, t);
+        else if (rem > 0) gather_batch<1>(q0, Q, j, t);
         wave_lds_fence();
     }
 
@@ -164,26 +169,67 @@ template <class T, int NC> struct RowEval {
         T p[SN];
 #pragma unroll
         for (int e = 0; e < SN; e++) p[e] = (T)0;
-        for (int t = 0; t < s_load; t++) {
-            const SA tv = row[t];
-            const SA av = avec[t];
+        // blocks of 4 slots with all 8 LDS reads issued before the first use, then the 0-3 left over
+        int t = 0;
+        for (; t + 4 <= s_load; t += 4) {
+            SA tv[4], av[4];
 #pragma unroll
-            for (int e = 0; e < SN; e++) p[e] = __builtin_fma(tv.v[e], av.v[e], p[e]);
+            for (int u = 0; u < 4; u++) { tv[u] = row[t + u]; av[u] = avec[t + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int e = 0; e < SN; e++) p[e] = fma_t(tv[u].v[e], av[u].v[e], p[e]);
+            }
+        }
+        {
+            const int rem = s_load - t;  // 0..3, wave-uniform
+            SA tv[3], av[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int tt = (u < rem) ? t + u : t;  // clamped: a repeated slot, multiplied by zero below
+                tv[u] = row[tt < s_load ? tt : 0];
+                av[u] = avec[tt < s_load ? tt : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                if (u < rem) {
+#pragma unroll
+                    for (int e = 0; e < SN; e++) p[e] = fma_t(tv[u].v[e], av[u].v[e], p[e]);
+                }
+            }
         }
         if constexpr (SN == 4) return (p[0] + p[1]) + (p[2] + p[3]);
         else return p[0] + p[1];
     }
 
-    // phase 2: acc_c += sum over the cnt nonzeros starting at jb of coef_j * T[j, c], in nonzero order
+    // phase 2: acc_c += sum over the cnt nonzeros starting at jb of coef_j * T[j, c], in nonzero order.
+    // Blocks of 8 are written out by hand: the loop contains a convergent operation (v_readlane), so the
+    // compiler will not unroll it on its own, and an un-unrolled body pays one full LDS latency per nonzero.
     __device__ __forceinline__ void accumulate(int jb, int cnt, T coef, T (&acc)[NC]) const
     {
-        const T* tf = (const T*)tile + (size_t)jb * (size_t)(s_stride * SN);
         const int rs = s_stride * SN;
-#pragma unroll 8
-        for (int jj = 0; jj < cnt; jj++) {
-            const T cj = read_lane(coef, jj);
+        const T* tf = (const T*)tile + (size_t)jb * (size_t)rs;
+        int jj = 0;
+        for (; jj + 8 <= cnt; jj += 8) {
+            T tv[8][NC];
+            T cj[8];
 #pragma unroll
-            for (int i = 0; i < NC; i++) acc[i] = __builtin_fma(cj, tf[jj * rs + coff[i]], acc[i]);
+            for (int u = 0; u < 8; u++) {
+#pragma unroll
+                for (int i = 0; i < NC; i++) tv[u][i] = tf[(jj + u) * rs + coff[i]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) cj[u] = read_lane(coef, jj + u);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+#pragma unroll
+                for (int i = 0; i < NC; i++) acc[i] = fma_t(cj[u], tv[u][i], acc[i]);
+            }
+        }
+        for (; jj < cnt; jj++) {
+            const T c1 = read_lane(coef, jj);
+#pragma unroll
+            for (int i = 0; i < NC; i++) acc[i] = fma_t(c1, tf[jj * rs + coff[i]], acc[i]);
         }
     }
 
@@ -229,7 +275,7 @@ template <class T, int NC> struct RowEval {
     {
         T s = (T)0;
 #pragma unroll
-        for (int i = 0; i < NC; i++) s = act[i] ? __builtin_fma(u[i], v[i], s) : s;
+        for (int i = 0; i < NC; i++) s = act[i] ? fma_t(u[i], v[i], s) : s;
         return wave_sum(s);
     }
     __device__ __forceinline__ T nrm2(const T (&u)[NC]) const { return (T)d_sqrt((double)dot(u, u)); }

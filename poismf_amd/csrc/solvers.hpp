@@ -41,7 +41,7 @@ __device__ __forceinline__ void pg_row(RowEval<T, NC>& ev, const RowParams<T>& P
         PMF_EW g[i] = (T)0;
         ev.template eval<false, true>((T)1, g);                   // calc_grad_pgd, ref: :126-133
         PMF_EW {
-            x[i] = __builtin_fma(P.step, g[i], x[i]);              // a += step * grad
+            x[i] = fma_t(P.step, g[i], x[i]);              // a += step * grad
             x[i] = x[i] + shift[i];                                // a += (pre-scaled) Bsum
             x[i] = x[i] * P.cnst_div;                              // a *= 1 / (1 + 2 l2 step)
             x[i] = (x[i] > (T)0) ? x[i] : (T)0;                    // a = max(a, 0)
@@ -74,7 +74,7 @@ __device__ __forceinline__ void grad_single(RowEval<T, NC>& ev, const RowParams<
     ev.set_point(a);
     const T two_l2 = (T)(2. * (double)P.l2);
     if (!weighted) {
-        PMF_EW g[i] = __builtin_fma(two_l2, a[i], bsum[i]);
+        PMF_EW g[i] = fma_t(two_l2, a[i], bsum[i]);
         ev.template eval<false, true>((T)-1, g);
     } else {
         PMF_EW g[i] = (T)0;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void grad_single(RowEval<T, NC>& ev, const RowParams<
         PMF_EW {
             g[i] = g[i] * P.w;
             g[i] = g[i] + bsum[i];
-            g[i] = __builtin_fma(two_l2, a[i], g[i]);
+            g[i] = fma_t(two_l2, a[i], g[i]);
         }
     }
 }
@@ -99,7 +99,7 @@ __device__ __forceinline__ T fun_and_grad(RowEval<T, NC>& ev, const RowParams<T>
     if (P.w != (T)1) { PMF_EW g[i] = g[i] * P.w; }
     PMF_EW g[i] = g[i] + bsum[i];
     const T reg = ev.dot(bsum, a);
-    PMF_EW g[i] = __builtin_fma(two_l2, a[i], g[i]);
+    PMF_EW g[i] = fma_t(two_l2, a[i], g[i]);
     return reg - lsum * P.w;
 }
 
@@ -155,7 +155,7 @@ __device__ __forceinline__ void cg_row(RowEval<T, NC>& ev, const RowParams<T>& P
         T step = max_step;
         for (int ls = 0; ls < max_ls; ls++) {                      // ref: :297-327
             PMF_EW {
-                trial[i] = __builtin_fma(step, d[i], x[i]);
+                trial[i] = fma_t(step, d[i], x[i]);
                 if (P.limit_step) trial[i] = ((double)trial[i] >= 1e-15) ? trial[i] : (T)0;   // quirk Q10
                 else              trial[i] = (trial[i] > (T)0) ? trial[i] : (T)0;
             }
@@ -539,8 +539,8 @@ template <class T, int NC> struct Tnc {
             }
             const T alpha = rz / vgv;
             PMF_EW {
-                zsol[i] = __builtin_fma(alpha, s.v[i], zsol[i]);
-                s.r[i] = __builtin_fma(-alpha, s.gv[i], s.r[i]);
+                zsol[i] = fma_t(alpha, s.v[i], zsol[i]);
+                s.r[i] = fma_t(-alpha, s.gv[i], s.r[i]);
             }
             const T gtp = ev.dot(zsol, s.g);
             const T pr = ev.dot(s.r, zsol);
@@ -548,7 +548,7 @@ template <class T, int NC> struct Tnc {
             const T qtest = (it + 1) * (1.0 - qold / qnew);
             if (qtest <= 0.5) break;
             if (gtp > 0.0) {
-                PMF_EW zsol[i] = __builtin_fma(-alpha, s.v[i], zsol[i]);
+                PMF_EW zsol[i] = fma_t(-alpha, s.v[i], zsol[i]);
                 break;
             }
             qold = qnew;
@@ -611,7 +611,7 @@ template <class T, int NC> struct Tnc {
         alpha = q.xmin;
         if (itest == PTC_OK) {
             f = q.fmin;
-            PMF_EW x[i] = __builtin_fma(alpha, p[i], x[i]);
+            PMF_EW x[i] = fma_t(alpha, p[i], x[i]);
             PMF_EW s.gfull[i] = newg[i];
             return LS_OK;
         }

@@ -96,6 +96,11 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Fused multiply-add in the working precision (__builtin_fma alone is the DOUBLE builtin: on floats it
+// would convert, do an f64 fma and convert back).
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // Double-typed libm wrappers.  The reference's C sources call fabs/sqrt/log/log10/fmin/fmax, which in
 // C are the DOUBLE functions even in its float build (USE_FLOAT); C++ overload resolution would pick
 // the float overloads and change the rounding of the surrounding expressions.
