@@ -265,11 +265,16 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass)
     g.k = (int)k;
     g.s_load = (int)((k * sizeof(real_t) + 15) / 16);
     g.s_stride = g.s_load | 1;
+    g.group = g.s_load <= 16 ? 16 : (g.s_load <= 32 ? 32 : 64);
     // tile capacity: whole rows of this bin if that fits the per-wave budget, else stream in chunks.
     // A single-pass solver (PG with one update) gains nothing from residency: keep tiles small there
     // so that many waves per CU keep gathers in flight.
     const unsigned want = std::max(16u, bin_max_nnz);
-    const unsigned stream_chunk = 128;
+    // chunk for streamed rows: ~14 KiB of tile per wave keeps >= 10 waves per CU gathering (measured on C2:
+    // 128-nonzero chunks 1.46 ms per sweep, 64 or 32: 0.80-0.85 ms)
+    unsigned stream_chunk = (unsigned)(14336 / ((size_t)g.s_stride * 16)) / 16 * 16;
+    stream_chunk = std::min(128u, std::max(16u, stream_chunk));
+    if (const char* e = getenv("POISMF_HIP_STREAM_CHUNK")) stream_chunk = (unsigned)std::max(16, atoi(e));  // tuning knob
     unsigned cap = want;
     g.resident = 1;
     TileGeom probe = g;
@@ -307,7 +312,15 @@ template <int NC> int launch_method(poismf_hip_session* s, int method, const Hal
     }
 }
 
-int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : 0)); }
+// column-sum kernels: elements per lane in the plain lane <-> element layout
+int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : (k <= 512 ? 8 : 0))); }
+// row kernels: 16-byte slots per lane (slot layout of row_eval.hpp); 0 = unsupported
+constexpr int SLOT_ELEMS = (int)(16 / sizeof(real_t));
+int slots_per_lane(size_t k)
+{
+    const size_t s_load = (k * sizeof(real_t) + 15) / 16;
+    return s_load <= 64 ? 1 : (s_load <= 128 ? 2 : 0);
+}
 
 template <int NC> int launch_colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
 {
@@ -325,6 +338,7 @@ int colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t s
         case 1: return launch_colsum<1>(s, M, n, l1, scale, nscale);
         case 2: return launch_colsum<2>(s, M, n, l1, scale, nscale);
         case 4: return launch_colsum<4>(s, M, n, l1, scale, nscale);
+        case 8: return launch_colsum<8>(s, M, n, l1, scale, nscale);
     }
     return 1;
 }
@@ -339,8 +353,8 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
                               size_t rowA_begin, size_t rowA_end, size_t rowB_begin, size_t rowB_end)
 {
     *out = nullptr;
-    if (nc_for_k(k) == 0 || k == 0) {
-        fprintf(stderr, "poismf_hip: k = %zu is outside the supported range 1..256\n", k);
+    if (k == 0 || slots_per_lane(k) == 0 || nc_for_k(k) == 0) {
+        fprintf(stderr, "poismf_hip: k = %zu is outside the supported range (1..%d)\n", k, 128 * SLOT_ELEMS);
         return 1;
     }
     if (rowA_end > dimA || rowB_end > dimB || rowA_begin > rowA_end || rowB_begin > rowB_end) return 1;
@@ -356,7 +370,7 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
     if (hipMalloc(&s->dB, dimB * k * sizeof(real_t) + slack) != hipSuccess) return fail();
     if (hipMemsetAsync(s->dA, 0, dimA * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (hipMemsetAsync(s->dB, 0, dimB * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
-    if (hipMalloc(&s->d_bsum, k * sizeof(real_t)) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_bsum, k * sizeof(real_t) + slack) != hipSuccess) return fail();
     if (hipMalloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t)) != hipSuccess) return fail();
     if (hipMalloc(&s->d_counter, sizeof(unsigned)) != hipSuccess) return fail();
     // half 0 updates B: rows of the CSC; half 1 updates A: rows of the CSR
@@ -480,12 +494,13 @@ int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_par
         a.geom = plan_geom(s->k, b.max_nnz, single_pass);
         const size_t lds = lds_bytes_per_wave(a.geom, sizeof(real_t));
         const unsigned waves_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / lds));
-        const unsigned grid = (unsigned)std::min<size_t>(b.count, (size_t)NUM_CU * waves_per_cu * 2);
+        unsigned grid_mult = 2;
+        if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
+        const unsigned grid = (unsigned)std::min<size_t>(b.count, (size_t)NUM_CU * waves_per_cu * grid_mult);
         int rc = 1;
-        switch (nc_for_k(s->k)) {
-            case 1: rc = launch_method<1>(s, p->method, a, lds, grid); break;
-            case 2: rc = launch_method<2>(s, p->method, a, lds, grid); break;
-            case 4: rc = launch_method<4>(s, p->method, a, lds, grid); break;
+        switch (slots_per_lane(s->k)) {
+            case 1: rc = launch_method<1 * SLOT_ELEMS>(s, p->method, a, lds, grid); break;
+            case 2: rc = launch_method<2 * SLOT_ELEMS>(s, p->method, a, lds, grid); break;
         }
         if (rc) return 1;
     }

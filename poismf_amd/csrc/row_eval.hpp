@@ -2,18 +2,25 @@
 //
 // One wavefront owns one output row r of the factor being updated (M) against the fixed opposing
 // factor F.  The rows F[ind_j] named by the row's nonzeros are gathered ONCE from HBM/L2 into an LDS
-// tile with 16-byte global loads (4-byte aligned, ~13 lanes per 200-byte row so every load
-// instruction moves up to 1 KiB) and every inner pass of the solver then runs from LDS:
+// tile with 16-byte global loads (4-/8-byte aligned; k = 50 fp32: 13 slots per 200-byte row, so every
+// load instruction moves 64 slots = 1 KiB) and every inner pass of the solver then runs from LDS.
 //
-//   phase 1  lane <-> nonzero : pred_j = T[j,:] . a     (ds_read_b128 of the lane's own tile row; the
-//                                                        row stride is an ODD number of 16-byte slots,
-//                                                        so the 16 lanes of a b128 group hit 16 slots)
-//   phase 2  lane <-> factor dimension : acc_c += coef_j * T[j,c] for j in nonzero order (conflict-free
-//                                                        ds_read, coef_j broadcast with v_readlane)
+// Register layout of every k-vector ("slot layout"): a lane holds whole 16-byte SLOTS (4 floats / 2
+// doubles), lane g of a group of G lanes holds slot g (+ G, + 2G .. when the row has more than 64
+// slots).  G = 16, 32 or 64 is the smallest power of two that covers the row, and the wave holds
+// JG = 64 / G identical COPIES of every vector, one per group.  Consequences:
+//   * k-length reductions are 4 DPP steps inside a 16-lane row (+1 / +3 cross-row combines for G = 32 / 64);
+//   * phase 2 below reads the tile with ds_read_b128 and lets the JG groups work on JG nonzeros at once.
+//
+//   phase 1  lane <-> nonzero : pred_j = T[j,:] . a   (ds_read_b128 down the lane's own tile row; the row
+//            stride is an ODD number of slots, so the 16 lanes of a b128 service group hit 16 distinct slots;
+//            `a` is broadcast from LDS), then coef_j = +-x_j / pred_j  and / or  x_j log(pred_j)
+//   phase 2  lane <-> (nonzero group, slot) : acc[slot] += coef_j * T[j, slot]  for the group's nonzeros
+//            j = jg, jg + JG, ..; the JG partial sums are combined once per evaluation
 //
 // which is what the reference does per nonzero with one ddot + one daxpy
 // (ref: src/poismf.c:126-133 calc_grad_pgd, :194-208 calc_fun_single, :210-240 calc_grad_single[_w],
-// :242-273 calc_fun_and_grad), but with no per-nonzero cross-lane reduction and no re-gather.
+// :242-273 calc_fun_and_grad), with no per-nonzero cross-lane reduction and no re-gather.
 // Rows that do not fit the tile (cap) are streamed chunk by chunk on every pass instead.
 #pragma once
 #include "wave_ops.hpp"
@@ -32,13 +39,14 @@ template <> struct Slot<double> {
     struct __attribute__((aligned(16))) A { double v[2]; };
 };
 
-// Geometry of one launch (host fills it in; see plan_launch in poismf_hip.hip).
+// Geometry of one launch (host fills it in; see plan_geom in poismf_hip.hip).
 struct TileGeom {
     int k;         // factor dimension
     int s_load;    // 16-byte slots actually holding data per factor row = ceil(k*sizeof(T)/16)
     int s_stride;  // LDS row stride in slots = s_load | 1 (odd: conflict-free ds_read_b128 down a column)
     int cap;       // nonzeros the tile can hold
     int resident;  // 1: every row of this launch has nnz <= cap, gather once per row
+    int group;     // G: lanes per vector copy (16, 32 or 64)
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t sizeof_real)
@@ -47,54 +55,108 @@ __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t s
     b += (size_t)g.s_load * 16;                          // current point a (padded with zeros)
     b += (((size_t)g.cap * sizeof_real) + 15) / 16 * 16; // x_j
     b += (((size_t)g.cap * 4) + 15) / 16 * 16;           // ind_j
+    b += 64 * sizeof_real;                               // coef_j of the 64 nonzeros in flight
     return b;
 }
 
+// NC = elements per lane = slots per lane (NS) x elements per slot.
 template <class T, int NC> struct RowEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
+    static constexpr int NS = NC / SN;
+    static_assert(NC % SN == 0, "a lane holds whole 16-byte slots");
 
     // LDS carve-out of this wave
     SA* tile;
     SA* avec;
     T* xb;
     unsigned* idxb;
+    T* coefb;
     // launch constants
     const T* F;
     int k, s_load, s_stride, cap, tail;
     bool resident;
-    int lane;
+    int lane, G, JG, g, jg;
     int gj0, gt0, gdj, gdt;  // lane -> (nonzero, slot) walk of the gather, advanced 64 slots at a time
-    int coff[NC];            // element offsets lane + 64 i clamped into the row
-    bool act[NC];            // lane + 64 i < k
+    int elem[NC];            // factor dimension held in element i of this lane
+    bool act[NC];            // elem[i] < k
+    int slotq[NS];           // slot index held in slot s of this lane, clamped into the row
+    bool slot_on[NS];
     // current row
     const unsigned* ind;
     const T* val;
     unsigned nnz;
 
-    __device__ __forceinline__ void init(const TileGeom& g, const T* F_, unsigned char* smem)
+    __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
         lane = lane_id();
         F = F_;
-        k = g.k; s_load = g.s_load; s_stride = g.s_stride; cap = g.cap; resident = g.resident != 0;
+        k = geo.k; s_load = geo.s_load; s_stride = geo.s_stride; cap = geo.cap; resident = geo.resident != 0;
+        G = geo.group; JG = WAVE / G;
+        g = lane & (G - 1); jg = lane / G;
         tail = k - (s_load - 1) * SN;  // valid elements in the last slot of a factor row (1..SN)
         unsigned char* p = smem;
         tile = (SA*)p; p += (size_t)cap * s_stride * 16;
         avec = (SA*)p; p += (size_t)s_load * 16;
         xb = (T*)p; p += (((size_t)cap * sizeof(T)) + 15) / 16 * 16;
-        idxb = (unsigned*)p;
+        idxb = (unsigned*)p; p += (((size_t)cap * 4) + 15) / 16 * 16;
+        coefb = (T*)p;
         gj0 = lane / s_load; gt0 = lane % s_load;
         gdj = WAVE / s_load; gdt = WAVE % s_load;
 #pragma unroll
-        for (int i = 0; i < NC; i++) {
-            const int c = lane + WAVE * i;
-            act[i] = c < k;
-            coff[i] = act[i] ? c : k - 1;
+        for (int s = 0; s < NS; s++) {
+            const int q = g + G * s;
+            slot_on[s] = q < s_load;
+            slotq[s] = slot_on[s] ? q : 0;
+#pragma unroll
+            for (int e = 0; e < SN; e++) {
+                elem[s * SN + e] = q * SN + e;
+                act[s * SN + e] = q * SN + e < k;
+            }
         }
-        // zero the padding of the point vector once; set_point only ever writes the first k entries
-        for (int c = k + lane; c < s_load * SN; c += WAVE) ((T*)avec)[c] = (T)0;
-        wave_lds_fence();
+    }
+
+    // ---- k-length vector helpers on the slot layout ------------------------------------------------
+    // reduce over ONE copy of a vector; every lane receives the (wave-uniform) result
+    template <class Op, class V> __device__ __forceinline__ V reduce(V x) const
+    {
+        x = Op::f(x, dpp_mov<0xB1>(x));
+        x = Op::f(x, dpp_mov<0x4E>(x));
+        x = Op::f(x, dpp_mov<0x141>(x));
+        x = Op::f(x, dpp_mov<0x140>(x));
+        if (G == 16) return uniform(x);
+        if (G == 32) return uniform(Op::f(read_lane(x, 0), read_lane(x, 16)));
+        const V r0 = read_lane(x, 0), r1 = read_lane(x, 16), r2 = read_lane(x, 32), r3 = read_lane(x, 48);
+        return uniform(Op::f(Op::f(r0, r1), Op::f(r2, r3)));
+    }
+    template <class V> __device__ __forceinline__ V rsum(V x) const { return reduce<OpSum>(x); }
+    template <class V> __device__ __forceinline__ V rmin(V x) const { return reduce<OpMin>(x); }
+    template <class V> __device__ __forceinline__ V rmax(V x) const { return reduce<OpMax>(x); }
+
+    __device__ __forceinline__ T dot(const T (&u)[NC], const T (&v)[NC]) const
+    {
+        T s = (T)0;
+#pragma unroll
+        for (int i = 0; i < NC; i++) s = act[i] ? fma_t(u[i], v[i], s) : s;
+        return rsum(s);
+    }
+    __device__ __forceinline__ T nrm2(const T (&u)[NC]) const { return (T)d_sqrt((double)dot(u, u)); }
+
+    // k-vector in global memory -> registers (every copy loads it; inactive elements read as 0)
+    __device__ __forceinline__ void load_vec(const T* p, T (&x)[NC]) const
+    {
+#pragma unroll
+        for (int i = 0; i < NC; i++) x[i] = act[i] ? p[elem[i]] : (T)0;
+    }
+    // registers -> global (copy 0 stores)
+    __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
+    {
+        if (jg == 0) {
+#pragma unroll
+            for (int i = 0; i < NC; i++)
+                if (act[i]) p[elem[i]] = x[i];
+        }
     }
 
     // One batch of the gather: UU x 64 consecutive 16-byte slots starting at slot q0.  All UU global loads
@@ -152,12 +214,21 @@ template <class T, int NC> struct RowEval {
         if (resident && nnz > 0) load_chunk(0, (int)nnz);
     }
 
-    // Publish the point at which the next evaluations happen.
+    // Publish the point at which the next evaluations happen (copy 0 writes its slots; the excess of the
+    // last slot is written as zero so that phase 1 can run over whole slots).
     __device__ __forceinline__ void set_point(const T (&x)[NC])
     {
+        if (jg == 0) {
 #pragma unroll
-        for (int i = 0; i < NC; i++)
-            if (act[i]) ((T*)avec)[lane + WAVE * i] = x[i];
+            for (int s = 0; s < NS; s++) {
+                if (slot_on[s]) {
+                    SA w;
+#pragma unroll
+                    for (int e = 0; e < SN; e++) w.v[e] = act[s * SN + e] ? x[s * SN + e] : (T)0;
+                    avec[slotq[s]] = w;
+                }
+            }
+        }
         wave_lds_fence();
     }
 
@@ -186,9 +257,9 @@ template <class T, int NC> struct RowEval {
             SA tv[3], av[3];
 #pragma unroll
             for (int u = 0; u < 3; u++) {
-                const int tt = (u < rem) ? t + u : t;  // clamped: a repeated slot, multiplied by zero below
-                tv[u] = row[tt < s_load ? tt : 0];
-                av[u] = avec[tt < s_load ? tt : 0];
+                const int tt = (u < rem) ? t + u : 0;
+                tv[u] = row[tt];
+                av[u] = avec[tt];
             }
 #pragma unroll
             for (int u = 0; u < 3; u++) {
@@ -202,44 +273,76 @@ template <class T, int NC> struct RowEval {
         else return p[0] + p[1];
     }
 
-    // phase 2: acc_c += sum over the cnt nonzeros starting at jb of coef_j * T[j, c], in nonzero order.
-    // Blocks of 8 are written out by hand: the loop contains a convergent operation (v_readlane), so the
-    // compiler will not unroll it on its own, and an un-unrolled body pays one full LDS latency per nonzero.
-    __device__ __forceinline__ void accumulate(int jb, int cnt, T coef, T (&acc)[NC]) const
+    // phase 2 for the cnt nonzeros starting at tile row jb whose coefficients are in coefb[0..cnt):
+    // group jg accumulates nonzeros jg, jg + JG, ...  (UNIT: coefficients are all 1, coefb is not read)
+    template <bool UNIT> __device__ __forceinline__ void accumulate(int jb, int cnt, T (&part)[NC]) const
     {
-        const int rs = s_stride * SN;
-        const T* tf = (const T*)tile + (size_t)jb * (size_t)rs;
-        int jj = 0;
-        for (; jj + 8 <= cnt; jj += 8) {
-            T tv[8][NC];
-            T cj[8];
+        const SA* base = tile + (size_t)jb * s_stride;
+        const int steps = (cnt + JG - 1) / JG;  // wave-uniform
+        int it = 0;
+        for (; it + 4 <= steps; it += 4) {
+            SA tv[4][NS];
+            T cj[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
+                const int j = (it + u) * JG + jg;
+                const bool ok = j < cnt;
+                const SA* row = base + (size_t)(ok ? j : cnt - 1) * s_stride;
+                if constexpr (UNIT) cj[u] = ok ? (T)1 : (T)0;
+                else cj[u] = ok ? coefb[j] : (T)0;
 #pragma unroll
-                for (int i = 0; i < NC; i++) tv[u][i] = tf[(jj + u) * rs + coff[i]];
+                for (int s = 0; s < NS; s++) tv[u][s] = row[slotq[s]];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) cj[u] = read_lane(coef, jj + u);
+            for (int u = 0; u < 4; u++) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+                for (int s = 0; s < NS; s++) {
 #pragma unroll
-                for (int i = 0; i < NC; i++) acc[i] = fma_t(cj[u], tv[u][i], acc[i]);
+                    for (int e = 0; e < SN; e++) part[s * SN + e] = fma_t(cj[u], tv[u][s].v[e], part[s * SN + e]);
+                }
             }
         }
-        for (; jj < cnt; jj++) {
-            const T c1 = read_lane(coef, jj);
+        for (; it < steps; it++) {
+            const int j = it * JG + jg;
+            const bool ok = j < cnt;
+            const SA* row = base + (size_t)(ok ? j : cnt - 1) * s_stride;
+            T c1;
+            if constexpr (UNIT) c1 = ok ? (T)1 : (T)0;
+            else c1 = ok ? coefb[j] : (T)0;
 #pragma unroll
-            for (int i = 0; i < NC; i++) acc[i] = fma_t(c1, tf[jj * rs + coff[i]], acc[i]);
+            for (int s = 0; s < NS; s++) {
+                const SA tv = row[slotq[s]];
+#pragma unroll
+                for (int e = 0; e < SN; e++) part[s * SN + e] = fma_t(c1, tv.v[e], part[s * SN + e]);
+            }
         }
+    }
+
+    // combine the JG per-group partial sums (fixed order, identical in every copy) and add them to acc
+    __device__ __forceinline__ void combine_groups(T (&part)[NC], T (&acc)[NC]) const
+    {
+        if (JG >= 2) {
+            if (JG == 4) {
+#pragma unroll
+                for (int i = 0; i < NC; i++) part[i] += __shfl_xor(part[i], 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NC; i++) part[i] += __shfl_xor(part[i], 32);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; i++) acc[i] += part[i];
     }
 
     // At the point last published with set_point:
     //   WANT_F : returns lsum = sum_j x_j log(pred_j)   (log and the sum in double, as the reference's
     //            `lsum += X[ix] * log(dot)` is a double expression even in its float build)
-    //   WANT_G : acc_c += sum_j (sgn x_j / pred_j) F[ind_j, c]  in nonzero order
+    //   WANT_G : acc_c += sum_j (sgn x_j / pred_j) F[ind_j, c]
     template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC])
     {
         double lpart = 0.0;
+        T part[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) part[i] = (T)0;
         for (unsigned c0 = 0; c0 < nnz; c0 += (unsigned)cap) {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
             if (!resident) load_chunk(c0, cn);
@@ -249,11 +352,14 @@ template <class T, int NC> struct RowEval {
                 const T xj = xb[on ? jb + lane : 0];
                 if constexpr (WANT_F) lpart += on ? (double)xj * d_log((double)pred) : 0.0;
                 if constexpr (WANT_G) {
-                    const T coef = on ? sgn * xj / pred : (T)0;
-                    accumulate(jb, cn - jb < WAVE ? cn - jb : WAVE, coef, acc);
+                    wave_lds_fence();  // previous sub-chunk's readers of coefb are done
+                    coefb[lane] = on ? sgn * xj / pred : (T)0;
+                    wave_lds_fence();
+                    accumulate<false>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
                 }
             }
         }
+        if constexpr (WANT_G) combine_groups(part, acc);
         if constexpr (WANT_F) return wave_sum(lpart);
         else return 0.0;
     }
@@ -262,34 +368,15 @@ template <class T, int NC> struct RowEval {
     // served from the tile instead of a second trip to memory)
     __device__ __forceinline__ void tile_colsum(T (&acc)[NC])
     {
+        T part[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) part[i] = (T)0;
         for (unsigned c0 = 0; c0 < nnz; c0 += (unsigned)cap) {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
             if (!resident) load_chunk(c0, cn);
-            for (int jb = 0; jb < cn; jb += WAVE)
-                accumulate(jb, cn - jb < WAVE ? cn - jb : WAVE, (T)1, acc);
+            for (int jb = 0; jb < cn; jb += WAVE) accumulate<true>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
         }
-    }
-
-    // ---- k-length vector helpers on the lane <-> dimension layout --------------------------------
-    __device__ __forceinline__ T dot(const T (&u)[NC], const T (&v)[NC]) const
-    {
-        T s = (T)0;
-#pragma unroll
-        for (int i = 0; i < NC; i++) s = act[i] ? fma_t(u[i], v[i], s) : s;
-        return wave_sum(s);
-    }
-    __device__ __forceinline__ T nrm2(const T (&u)[NC]) const { return (T)d_sqrt((double)dot(u, u)); }
-
-    __device__ __forceinline__ void load_vec(const T* p, T (&x)[NC]) const
-    {
-#pragma unroll
-        for (int i = 0; i < NC; i++) x[i] = act[i] ? p[lane + WAVE * i] : (T)0;
-    }
-    __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
-    {
-#pragma unroll
-        for (int i = 0; i < NC; i++)
-            if (act[i]) p[lane + WAVE * i] = x[i];
+        combine_groups(part, acc);
     }
 };
 

@@ -1,7 +1,7 @@
 // solvers.hpp -- the three per-row inner solvers as wave-resident state machines.
 //
-// State vectors live in registers in the lane <-> factor-dimension layout (NC = ceil(k/64) elements per
-// lane); every scalar is wave-uniform, so every data-dependent branch of the line searches is a scalar
+// State vectors live in registers in the slot layout of row_eval.hpp (NC elements per lane = whole 16-byte
+// slots, JG identical copies per wave); every scalar is wave-uniform, so every data-dependent branch of the line searches is a scalar
 // branch with no divergence.  Arithmetic follows the reference statement by statement, including the
 // places where its C sources promote to double inside the float build.
 //
@@ -131,7 +131,7 @@ __device__ __forceinline__ void cg_row(RowEval<T, NC>& ev, const RowParams<T>& P
                 th += on ? g[i] * dp[i] : (T)0;
                 be += on ? g[i] * (g[i] - gp[i]) : (T)0;
             }
-            T theta = wave_sum(th), beta = wave_sum(be);
+            T theta = ev.rsum(th), beta = ev.rsum(be);
             theta /= gprev_sq;
             beta /= gprev_sq;
             PMF_EW d[i] += (x[i] <= (T)0) ? (T)0 : beta * dp[i] - theta * (g[i] - gp[i]);
@@ -143,11 +143,11 @@ __device__ __forceinline__ void cg_row(RowEval<T, NC>& ev, const RowParams<T>& P
         if (P.limit_step) {
             T m = (T)1;
             PMF_EW if (ev.act[i] && d[i] < (T)0) m = (T)d_min((double)m, (double)(-x[i] / d[i]));
-            max_step = wave_min(m);
+            max_step = ev.rmin(m);
         } else {
             T m = (T)0;
             PMF_EW if (ev.act[i] && d[i] < (T)0) m = (T)d_max((double)m, (double)(-x[i] / d[i]));
-            max_step = wave_max(m);
+            max_step = ev.rmax(m);
             max_step = (T)d_min(1., 0.99 * (double)max_step);
         }
 
@@ -717,7 +717,7 @@ template <class T, int NC> struct Tnc {
                         if (t > ustpmax * s.pk[i]) m = (T)d_min((double)m, (double)(t / s.pk[i]));
                     }
                 }
-                spe = wave_min(m);
+                spe = ev.rmin(m);
             }
 
             if (spe > 0.0) {
@@ -751,7 +751,7 @@ template <class T, int NC> struct Tnc {
                         }
                     }
                 }
-                added = wave_max((int)added) != 0;
+                added = ev.rmax((int)added) != 0;
                 if (!added && s.nfeval == oldnfeval) { rc = T_NOPROGRESS; break; }
                 fLastConstraint = f;
             }
@@ -777,13 +777,13 @@ template <class T, int NC> struct Tnc {
                 PMF_EW {
                     if (ev.act[i] && s.pivot[i] != 2) {
                         const T t = -s.pivot[i] * s.g[i];
-                        if (t < best) { best = t; besti = ev.lane + WAVE * i; }
+                        if (t < best) { best = t; besti = ev.elem[i]; }
                     }
                 }
-                const T cmax = wave_min(best);
+                const T cmax = ev.rmin(best);
                 if (cmax < 0.0) {
-                    const int imax = wave_min((best == cmax) ? besti : 0x7fffffff);
-                    PMF_EW if (ev.lane + WAVE * i == imax) s.pivot[i] = 0;
+                    const int imax = ev.rmin((best == cmax) ? besti : 0x7fffffff);
+                    PMF_EW if (ev.elem[i] == imax) s.pivot[i] = 0;
                     remcon = true;
                 }
             }

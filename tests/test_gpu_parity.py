@@ -141,6 +141,16 @@ def test_medium_vs_oracle(prec, method, k, numiter):
     kw = dict(maxupd=60) if method == "tncg" else {}
     A, B, args = gpu_run(csr, csc, A0, B0, method, numiter, k, **kw)
     Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
+    if method == "pg" and prec and np.isfinite(Ar).all():
+        # rows here reach ~10^4 nonzeros: in fp32 two summation orders legitimately differ by ~sqrt(nnz) eps, more
+        # than the 1e-5 that holds for short rows.  Judge both fp32 results against the fp64 oracle instead: the
+        # GPU must be at least as close to it as the fp32 oracle is (factor 2 margin).
+        csr64, csc64 = tuple((c[0].astype(np.float64), c[1], c[2]) for c in (csr, csc))
+        A64, B64 = oracle_run(False, csr64, csc64, A0.astype(np.float64), B0.astype(np.float64), method, args)
+        for X, Xr, X64 in ((A, Ar, A64), (B, Br, B64)):
+            assert H.scaled_err(X, X64) <= max(2.0 * H.scaled_err(Xr, X64), 1e-5)
+            assert H.scaled_err(X, Xr) <= 1e-4
+        return
     compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
 
 
