@@ -45,11 +45,11 @@ enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
 
 // One wavefront (= one 64-thread workgroup, so no workgroup barrier is ever needed and the LDS tile
 // is private) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the nnz-sorted permutation.
-template <class T, int NC, int METHOD>
+template <class T, int NC, int METHOD, int SL>
 __global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    RowEval<T, NC> ev;
+    RowEval<T, NC, SL> ev;
     ev.init(a.geom, a.F, smem);
     const int k = a.geom.k;
     T bs[NC];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
             T prev[NC];
             PMF_EW prev[i] = x[i];
             if (!a.reuse_prev) { PMF_EW x[i] = (T)1e-3; }                   // ref: src/poismf.c:379-381
-            (void)Tnc<T, NC>::minimize(ev, a.P, shift, x);
+            (void)Tnc<T, NC, SL>::minimize(ev, a.P, shift, x);
             if (a.early_stop) {                                             // ref: src/poismf.c:393-396
                 PMF_EW prev[i] = prev[i] - x[i];
                 const T moved = ev.dot(prev, prev);
@@ -289,9 +289,9 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass)
     return g;
 }
 
-template <int NC, int METHOD> int launch_bin(poismf_hip_session* s, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+template <int NC, int METHOD, int SL> int launch_bin(poismf_hip_session* s, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
 {
-    auto kern = half_sweep_kernel<real_t, NC, METHOD>;
+    auto kern = half_sweep_kernel<real_t, NC, METHOD, SL>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -303,14 +303,22 @@ template <int NC, int METHOD> int launch_bin(poismf_hip_session* s, const HalfAr
     return 0;
 }
 
-template <int NC> int launch_method(poismf_hip_session* s, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+template <int NC, int SL> int launch_method(poismf_hip_session* s, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
 {
     switch (method) {
-        case POISMF_PG: return launch_bin<NC, K_PG>(s, a, lds, grid);
-        case POISMF_CG: return launch_bin<NC, K_CG>(s, a, lds, grid);
-        default: return launch_bin<NC, K_TNCG>(s, a, lds, grid);
+        case POISMF_PG: return launch_bin<NC, K_PG, SL>(s, a, lds, grid);
+        case POISMF_CG: return launch_bin<NC, K_CG, SL>(s, a, lds, grid);
+        default: return launch_bin<NC, K_TNCG, SL>(s, a, lds, grid);
     }
 }
+
+// Slot counts with a compile-time specialisation: the k values of the BASELINE configs
+// (fp32: k = 49..52 -> 13 slots, k = 97..100 -> 25; fp64: k = 49..50 -> 25, k = 99..100 -> 50).
+#ifdef USE_FLOAT
+constexpr int SPECIAL_SL_A = 13, SPECIAL_SL_B = 25;
+#else
+constexpr int SPECIAL_SL_A = 25, SPECIAL_SL_B = 50;
+#endif
 
 // column-sum kernels: elements per lane in the plain lane <-> element layout
 int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : (k <= 512 ? 8 : 0))); }
@@ -498,9 +506,12 @@ int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_par
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(b.count, (size_t)NUM_CU * waves_per_cu * grid_mult);
         int rc = 1;
-        switch (slots_per_lane(s->k)) {
-            case 1: rc = launch_method<1 * SLOT_ELEMS>(s, p->method, a, lds, grid); break;
-            case 2: rc = launch_method<2 * SLOT_ELEMS>(s, p->method, a, lds, grid); break;
+        static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
+        if (!generic_only && a.geom.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A>(s, p->method, a, lds, grid);
+        else if (!generic_only && a.geom.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B>(s, p->method, a, lds, grid);
+        else switch (slots_per_lane(s->k)) {
+            case 1: rc = launch_method<1 * SLOT_ELEMS, 0>(s, p->method, a, lds, grid); break;
+            case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(s, p->method, a, lds, grid); break;
         }
         if (rc) return 1;
     }

@@ -60,7 +60,11 @@ __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t s
 }
 
 // NC = elements per lane = slots per lane (NS) x elements per slot.
-template <class T, int NC> struct RowEval {
+// SL > 0 fixes the number of 16-byte slots per factor row at compile time (specialisations for the k values of
+// the BASELINE configs): the row stride, group size and every LDS offset of the two phases then fold into
+// instruction immediates, which removes most of the address arithmetic (measured: 85 % of the issued
+// instructions of the generic phase-2 loop were address / mask bookkeeping).  SL = 0 is the generic kernel.
+template <class T, int NC, int SL = 0> struct RowEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
@@ -92,8 +96,13 @@ template <class T, int NC> struct RowEval {
     {
         lane = lane_id();
         F = F_;
-        k = geo.k; s_load = geo.s_load; s_stride = geo.s_stride; cap = geo.cap; resident = geo.resident != 0;
-        G = geo.group; JG = WAVE / G;
+        k = geo.k; cap = geo.cap; resident = geo.resident != 0;
+        if constexpr (SL > 0) {  // compile-time geometry (the host only launches this instance when it matches)
+            s_load = SL; s_stride = SL | 1; G = SL <= 16 ? 16 : (SL <= 32 ? 32 : 64);
+        } else {
+            s_load = geo.s_load; s_stride = geo.s_stride; G = geo.group;
+        }
+        JG = WAVE / G;
         g = lane & (G - 1); jg = lane / G;
         tail = k - (s_load - 1) * SN;  // valid elements in the last slot of a factor row (1..SN)
         unsigned char* p = smem;
@@ -237,85 +246,95 @@ template <class T, int NC> struct RowEval {
     {
         const int j = jb + lane;
         const SA* row = tile + (size_t)(j < cn ? j : cn - 1) * s_stride;
-        T p[SN];
+        // explicit 2-wide vectors so that the float build lowers to v_pk_fma_f32 on the register pairs the
+        // ds_read_b128 results already sit in (left to itself the vectoriser pairs lanes (0,2),(1,3) and pays
+        // three v_mov per packed FMA)
+        typedef T V2 __attribute__((ext_vector_type(2)));
+        constexpr int H = SN / 2;
+        V2 p[H];
 #pragma unroll
-        for (int e = 0; e < SN; e++) p[e] = (T)0;
-        // blocks of 4 slots with all 8 LDS reads issued before the first use, then the 0-3 left over
+        for (int h = 0; h < H; h++) p[h] = (V2)(T)0;
+        // Blocks of 8 slots: all 16 LDS reads of a block are in flight before the first FMA (at 1-2 waves per
+        // SIMD nothing else hides LDS latency), then one masked block for the 0-7 slots left over.
         int t = 0;
-        for (; t + 4 <= s_load; t += 4) {
-            SA tv[4], av[4];
+        for (; t + 8 <= s_load; t += 8) {
+            SA tv[8], av[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { tv[u] = row[t + u]; av[u] = avec[t + u]; }
+            for (int u = 0; u < 8; u++) { tv[u] = row[t + u]; av[u] = avec[t + u]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
 #pragma unroll
-                for (int e = 0; e < SN; e++) p[e] = fma_t(tv[u].v[e], av[u].v[e], p[e]);
+                for (int h = 0; h < H; h++)
+                    p[h] = __builtin_elementwise_fma((V2){ tv[u].v[2 * h], tv[u].v[2 * h + 1] },
+                                                     (V2){ av[u].v[2 * h], av[u].v[2 * h + 1] }, p[h]);
             }
         }
         {
-            const int rem = s_load - t;  // 0..3, wave-uniform
-            SA tv[3], av[3];
+            const int rem = s_load - t;  // 0..7, wave-uniform
+            SA tv[7], av[7];
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-                const int tt = (u < rem) ? t + u : 0;
-                tv[u] = row[tt];
-                av[u] = avec[tt];
+            for (int u = 0; u < 7; u++) {
+                if (u < rem) { tv[u] = row[t + u]; av[u] = avec[t + u]; }
             }
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
+            for (int u = 0; u < 7; u++) {
                 if (u < rem) {
 #pragma unroll
-                    for (int e = 0; e < SN; e++) p[e] = fma_t(tv[u].v[e], av[u].v[e], p[e]);
+                    for (int h = 0; h < H; h++)
+                        p[h] = __builtin_elementwise_fma((V2){ tv[u].v[2 * h], tv[u].v[2 * h + 1] },
+                                                         (V2){ av[u].v[2 * h], av[u].v[2 * h + 1] }, p[h]);
                 }
             }
         }
-        if constexpr (SN == 4) return (p[0] + p[1]) + (p[2] + p[3]);
-        else return p[0] + p[1];
+        if constexpr (SN == 4) return (p[0].x + p[0].y) + (p[1].x + p[1].y);
+        else return p[0].x + p[0].y;
     }
 
-    // phase 2 for the cnt nonzeros starting at tile row jb whose coefficients are in coefb[0..cnt):
-    // group jg accumulates nonzeros jg, jg + JG, ...  (UNIT: coefficients are all 1, coefb is not read)
+    // coefficient buffer layout: the 64 nonzeros of the sub-chunk in flight, transposed so that group jg finds
+    // the coefficients of ITS nonzeros (jg, jg + JG, ...) contiguously: coefb[jg * (64 / JG) + step]
+    __device__ __forceinline__ int coef_slot(int j) const { return (j % JG) * (WAVE / JG) + j / JG; }
+
+    // UB steps of phase 2 starting at step `it`.  MASKED = false: every nonzero touched exists, so the UB tile
+    // rows are at constant strides from one base address; MASKED = true (tail): rows past the end are clamped to
+    // the last valid row (their coefficient is zero, the tile beyond the chunk may hold anything).
+    template <bool UNIT, int UB, bool MASKED> __device__ __forceinline__ void accumulate_block(const SA* base, int it, int cnt,
+                                                                                               T (&part)[NC]) const
+    {
+        SA tv[UB][NS];
+        T cj[UB];
+        const T* cf = coefb + jg * (WAVE / JG) + it;
+        const SA* row0 = base + (size_t)(it * JG + jg) * s_stride;
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int j = (it + u) * JG + jg;
+            const SA* row = row0 + (size_t)(u * JG) * s_stride;
+            if constexpr (MASKED) row = base + (size_t)(j < cnt ? j : cnt - 1) * s_stride;
+            if constexpr (UNIT) cj[u] = (!MASKED || j < cnt) ? (T)1 : (T)0;
+            else cj[u] = cf[u];
+#pragma unroll
+            for (int s = 0; s < NS; s++) tv[u][s] = row[slotq[s]];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+#pragma unroll
+                for (int e = 0; e < SN; e++) part[s * SN + e] = fma_t(cj[u], tv[u][s].v[e], part[s * SN + e]);
+            }
+        }
+    }
+    // phase 2 for the cnt (<= 64) nonzeros starting at tile row jb whose coefficients are in coefb:
+    // group jg accumulates nonzeros jg, jg + JG, ...  (UNIT: all coefficients are 1, coefb is not read)
     template <bool UNIT> __device__ __forceinline__ void accumulate(int jb, int cnt, T (&part)[NC]) const
     {
         const SA* base = tile + (size_t)jb * s_stride;
-        const int steps = (cnt + JG - 1) / JG;  // wave-uniform
+        const int full = cnt / JG;              // steps in which every group has a nonzero (wave-uniform)
+        const int steps = (cnt + JG - 1) / JG;
         int it = 0;
-        for (; it + 4 <= steps; it += 4) {
-            SA tv[4][NS];
-            T cj[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = (it + u) * JG + jg;
-                const bool ok = j < cnt;
-                const SA* row = base + (size_t)(ok ? j : cnt - 1) * s_stride;
-                if constexpr (UNIT) cj[u] = ok ? (T)1 : (T)0;
-                else cj[u] = ok ? coefb[j] : (T)0;
-#pragma unroll
-                for (int s = 0; s < NS; s++) tv[u][s] = row[slotq[s]];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-#pragma unroll
-                for (int s = 0; s < NS; s++) {
-#pragma unroll
-                    for (int e = 0; e < SN; e++) part[s * SN + e] = fma_t(cj[u], tv[u][s].v[e], part[s * SN + e]);
-                }
-            }
-        }
-        for (; it < steps; it++) {
-            const int j = it * JG + jg;
-            const bool ok = j < cnt;
-            const SA* row = base + (size_t)(ok ? j : cnt - 1) * s_stride;
-            T c1;
-            if constexpr (UNIT) c1 = ok ? (T)1 : (T)0;
-            else c1 = ok ? coefb[j] : (T)0;
-#pragma unroll
-            for (int s = 0; s < NS; s++) {
-                const SA tv = row[slotq[s]];
-#pragma unroll
-                for (int e = 0; e < SN; e++) part[s * SN + e] = fma_t(c1, tv.v[e], part[s * SN + e]);
-            }
-        }
+        for (; it + 16 <= full; it += 16) accumulate_block<UNIT, 16, false>(base, it, cnt, part);
+        if (it + 8 <= full) { accumulate_block<UNIT, 8, false>(base, it, cnt, part); it += 8; }
+        if (it + 4 <= full) { accumulate_block<UNIT, 4, false>(base, it, cnt, part); it += 4; }
+        if (it < steps) accumulate_block<UNIT, 4, true>(base, it, cnt, part);   // <= 3 full steps + a partial one
     }
 
     // combine the JG per-group partial sums (fixed order, identical in every copy) and add them to acc
@@ -353,7 +372,7 @@ template <class T, int NC> struct RowEval {
                 if constexpr (WANT_F) lpart += on ? (double)xj * d_log((double)pred) : 0.0;
                 if constexpr (WANT_G) {
                     wave_lds_fence();  // previous sub-chunk's readers of coefb are done
-                    coefb[lane] = on ? sgn * xj / pred : (T)0;
+                    coefb[coef_slot(lane)] = on ? sgn * xj / pred : (T)0;
                     wave_lds_fence();
                     accumulate<false>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
                 }
