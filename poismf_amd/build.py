@@ -22,6 +22,7 @@ def _stale(out):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    procs = []
     for use_float in (False, True):
         out = lib_path(use_float)
         if not force and not _stale(out):
@@ -33,7 +34,10 @@ def build(force=False, verbose=False):
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))  # the two precisions compile side by side
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     return lib_path(False), lib_path(True)
 
 

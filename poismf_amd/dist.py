@@ -57,7 +57,9 @@ def exchange_shards(full, ranges, rank, group=None):
     sizes = {e - b for b, e in ranges}
     if len(sizes) == 1 and ranges[0][0] == 0 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)):
         b, e = ranges[rank]
-        dist.all_gather_into_tensor(full, full[b:e], group=group)
+        # staged through a copy of the shard rather than gathered in place: the extra copy is the size of one
+        # shard (C4 A half: 25 MB, ~10 us of HBM time) and avoids relying on in-place aliasing rules
+        dist.all_gather_into_tensor(full, full[b:e].clone(), group=group)
         return
     for owner, (b, e) in enumerate(ranges):
         if e > b:
