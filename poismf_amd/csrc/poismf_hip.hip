@@ -89,7 +89,8 @@ __global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
         if constexpr (METHOD == K_PG) {
             pg_row(ev, a.P, x, shift);
         } else if constexpr (METHOD == K_CG) {
-            cg_row(ev, a.P, shift, x, weighted);
+            if (a.P.limit_step && ev.pq_cap > 0 && nnz <= (unsigned)ev.pq_cap) cg_row_cached(ev, a.P, shift, x, weighted);  // streamed rows only, see plan_geom
+            else cg_row(ev, a.P, shift, x, weighted);
         } else {
             T prev[NC];
             PMF_EW prev[i] = x[i];
@@ -263,10 +264,11 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     return 0;
 }
 
-TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass)
+TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_pq)
 {
     TileGeom g;
     g.k = (int)k;
+    g.pq_cap = 0;
     g.s_load = (int)((k * sizeof(real_t) + 15) / 16);
     g.s_stride = g.s_load | 1;
     g.group = g.s_load <= 16 ? 16 : (g.s_load <= 32 ? 32 : 64);
@@ -290,6 +292,14 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass)
         g.resident = 0;
     }
     g.cap = (int)cap;
+    // CG: cache T.x and T.d per nonzero when both fit next to the tile (up to 48 KiB for the pair); longer rows
+    // fall back to the direct line search
+    static const bool no_cache = getenv("POISMF_HIP_CG_NOCACHE") != nullptr;  // testing knob
+    // Only for streamed rows: there every line-search trial would otherwise be a fresh gather from L2/HBM
+    // (C3 B half: 247 -> 146 ms).  For LDS-resident rows a trial is a cheap pass over the tile already and the
+    // extra q = T.d pass makes the cached variant slightly slower (C2: 10.3 -> 10.9 ms), so they keep the direct one.
+    if (want_pq && !no_cache && !g.resident && (size_t)2 * bin_max_nnz * sizeof(real_t) <= 48 * 1024)
+        g.pq_cap = (int)((bin_max_nnz + 15u) / 16u * 16u);
     return g;
 }
 
@@ -505,10 +515,11 @@ int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_par
     struct Launch { unsigned begin, count; TileGeom geom; };
     std::vector<Launch> launches;
     for (const Bin& b : h.bins) {
-        TileGeom g = plan_geom(s->k, b.max_nnz, single_pass);
+        TileGeom g = plan_geom(s->k, b.max_nnz, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) g.resident = 0;  // one pass: "gather once" and "stream" are the same thing
         if (!launches.empty() && launches.back().geom.cap == g.cap && launches.back().geom.resident == g.resident &&
-            (g.resident == 0) && launches.back().begin + launches.back().count == b.begin)
+            (g.resident == 0) && g.pq_cap == 0 && launches.back().geom.pq_cap == 0 &&
+            launches.back().begin + launches.back().count == b.begin)
             launches.back().count += b.count;
         else
             launches.push_back({ b.begin, b.count, g });

@@ -47,6 +47,7 @@ struct TileGeom {
     int cap;       // nonzeros the tile can hold
     int resident;  // 1: every row of this launch has nnz <= cap, gather once per row
     int group;     // G: lanes per vector copy (16, 32 or 64)
+    int pq_cap;    // nonzeros for which the two per-nonzero prediction caches (T.x, T.d) fit in LDS; 0 = no cache
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t sizeof_real)
@@ -56,6 +57,7 @@ __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t s
     b += (((size_t)g.cap * sizeof_real) + 15) / 16 * 16; // x_j
     b += (((size_t)g.cap * 4) + 15) / 16 * 16;           // ind_j
     b += 64 * sizeof_real;                               // coef_j of the 64 nonzeros in flight
+    b += (((size_t)2 * g.pq_cap * sizeof_real) + 15) / 16 * 16;  // cached predictions p_j = T_j.x and q_j = T_j.d
     return b;
 }
 
@@ -77,6 +79,9 @@ template <class T, int NC, int SL = 0> struct RowEval {
     T* xb;
     unsigned* idxb;
     T* coefb;
+    T* pbuf;  // p_j = F[ind_j,:] . x   for every nonzero of the row (CG line-search cache)
+    T* qbuf;  // q_j = F[ind_j,:] . d
+    int pq_cap;
     // launch constants
     const T* F;
     int k, s_load, s_stride, cap, tail;
@@ -110,7 +115,9 @@ template <class T, int NC, int SL = 0> struct RowEval {
         avec = (SA*)p; p += (size_t)s_load * 16;
         xb = (T*)p; p += (((size_t)cap * sizeof(T)) + 15) / 16 * 16;
         idxb = (unsigned*)p; p += (((size_t)cap * 4) + 15) / 16 * 16;
-        coefb = (T*)p;
+        coefb = (T*)p; p += 64 * sizeof(T);
+        pq_cap = geo.pq_cap;
+        pbuf = (T*)p; qbuf = pbuf + pq_cap;
         gj0 = lane / s_load; gt0 = lane % s_load;
         gdj = WAVE / s_load; gdt = WAVE % s_load;
 #pragma unroll
@@ -356,7 +363,8 @@ template <class T, int NC, int SL = 0> struct RowEval {
     //   WANT_F : returns lsum = sum_j x_j log(pred_j)   (log and the sum in double, as the reference's
     //            `lsum += X[ix] * log(dot)` is a double expression even in its float build)
     //   WANT_G : acc_c += sum_j (sgn x_j / pred_j) F[ind_j, c]
-    template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC])
+    //   store  : if not null, pred_j is also written to store[j] for every nonzero j of the row
+    template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
     {
         double lpart = 0.0;
         T part[NC];
@@ -369,6 +377,7 @@ template <class T, int NC, int SL = 0> struct RowEval {
                 const T pred = pred_lane(jb, cn);
                 const bool on = jb + lane < cn;
                 const T xj = xb[on ? jb + lane : 0];
+                if (store != nullptr && on) store[c0 + jb + lane] = pred;
                 if constexpr (WANT_F) lpart += on ? (double)xj * d_log((double)pred) : 0.0;
                 if constexpr (WANT_G) {
                     wave_lds_fence();  // previous sub-chunk's readers of coefb are done
@@ -379,8 +388,28 @@ template <class T, int NC, int SL = 0> struct RowEval {
             }
         }
         if constexpr (WANT_G) combine_groups(part, acc);
+        if (store != nullptr) wave_lds_fence();
         if constexpr (WANT_F) return wave_sum(lpart);
         else return 0.0;
+    }
+
+    // sum_j x_j log(p_j + alpha q_j) from the cached predictions: no access to the tile or to F at all.
+    // This is the evaluation the reference's authors describe as the faster alternative for line searches
+    // (ref: src/poismf.c:191-193, src/nonnegcg.c:291-294).
+    __device__ __forceinline__ double logsum_cached(T alpha) const
+    {
+        double lpart = 0.0;
+        for (unsigned j = lane; j < nnz; j += WAVE) {
+            const T pred = fma_t(alpha, qbuf[j], pbuf[j]);
+            lpart += (double)val[j] * d_log((double)pred);
+        }
+        return wave_sum(lpart);
+    }
+    // after an accepted step x <- x + alpha d the cached T.x moves along with it
+    __device__ __forceinline__ void advance_cached(T alpha)
+    {
+        for (unsigned j = lane; j < nnz; j += WAVE) pbuf[j] = fma_t(alpha, qbuf[j], pbuf[j]);
+        wave_lds_fence();
     }
 
     // acc_c += sum_j F[ind_j, c]   (the gather pass of adjustment_Bsum, ref: src/poismf.c:108-110,

@@ -174,6 +174,100 @@ __device__ __forceinline__ void cg_row(RowEval<T, NC, SL>& ev, const RowParams<T
     }
 }
 
+// The same solver with the line search evaluated from cached predictions.  With limit_step the trial point
+// x + alpha d stays feasible for alpha <= max_step (only components that land below 1e-15 are snapped to 0), so
+// F_j . trial = F_j . x + alpha F_j . d up to <= 1e-15 |F_j|: per CG iteration the tile is read twice (gradient at
+// x with p = T.x stored on the way, then q = T.d) and every Armijo trial costs nnz fused-multiply-adds and logs
+// instead of another pass over the tile -- for rows that do not fit in LDS that is 2 gathers per iteration
+// instead of ~6.  Arithmetic differs from the direct evaluation by rounding only (p + alpha q vs a fresh dot).
+template <class T, int NC, int SL>
+__device__ __forceinline__ void cg_row_cached(RowEval<T, NC, SL>& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC],
+                                              bool weighted)
+{
+    const T tol = (T)1e-2, decr = (T)0.25, c_ls = (T)0.01;
+    const int maxnfeval = 150, max_ls = 20;
+    const int maxiter = P.maxupd > 0 ? P.maxupd : 0x7fffffff;
+    const T two_l2 = (T)(2. * (double)P.l2);
+    T g[NC], d[NC], gp[NC], dp[NC], trial[NC], dummy[NC];
+    PMF_EW { gp[i] = (T)0; dp[i] = (T)0; dummy[i] = (T)0; }
+    T gprev_sq = (T)0;
+
+    // f0 = f(x), keeping p = T.x                                              ref: src/nonnegcg.c:191
+    ev.set_point(x);
+    T reg = ev.dot(bsum, x);
+    reg += P.l2 * ev.dot(x, x);
+    T f_cur = reg - (T)ev.template eval<true, false>((T)0, dummy, ev.pbuf) * P.w;
+    T f_new = (T)0;
+    int nfeval = 1;
+    if (not_finite(f_cur)) return;
+    bool p_fresh = true;  // pbuf == T.x exactly (just computed) rather than advanced by p += alpha q
+
+    for (int it = 0; it < maxiter; it++) {
+        // gradient at x; the same pass refreshes p = T.x unless it is already exact
+        ev.set_point(x);
+        if (!weighted) {
+            PMF_EW g[i] = fma_t(two_l2, x[i], bsum[i]);
+            ev.template eval<false, true>((T)-1, g, p_fresh ? nullptr : ev.pbuf);
+        } else {
+            PMF_EW g[i] = (T)0;
+            ev.template eval<false, true>((T)-1, g, p_fresh ? nullptr : ev.pbuf);
+            PMF_EW {
+                g[i] = g[i] * P.w;
+                g[i] = g[i] + bsum[i];
+                g[i] = fma_t(two_l2, x[i], g[i]);
+            }
+        }
+        PMF_EW d[i] = (x[i] <= (T)0 && g[i] >= (T)0) ? (T)0 : -g[i];
+        if (it > 0) {
+            T th = (T)0, be = (T)0;
+            PMF_EW {
+                const bool on = ev.act[i] && !(x[i] <= (T)0);
+                th += on ? g[i] * dp[i] : (T)0;
+                be += on ? g[i] * (g[i] - gp[i]) : (T)0;
+            }
+            T theta = ev.rsum(th), beta = ev.rsum(be);
+            theta /= gprev_sq;
+            beta /= gprev_sq;
+            PMF_EW d[i] += (x[i] <= (T)0) ? (T)0 : beta * dp[i] - theta * (g[i] - gp[i]);
+        }
+        const T gd = ev.dot(g, d);
+        if (d_abs((double)gd) <= (double)tol) return;
+
+        T m = (T)1;
+        PMF_EW if (ev.act[i] && d[i] < (T)0) m = (T)d_min((double)m, (double)(-x[i] / d[i]));
+        const T max_step = ev.rmin(m);
+
+        // q = T.d (second and last pass over the tile in this iteration)
+        ev.set_point(d);
+        (void)ev.template eval<false, false>((T)0, dummy, ev.qbuf);
+
+        const T dd = ev.dot(d, d);
+        T step = max_step;
+        bool accepted = false;
+        for (int ls = 0; ls < max_ls; ls++) {
+            PMF_EW {
+                trial[i] = fma_t(step, d[i], x[i]);
+                trial[i] = ((double)trial[i] >= 1e-15) ? trial[i] : (T)0;
+            }
+            T r = ev.dot(bsum, trial);
+            r += P.l2 * ev.dot(trial, trial);
+            f_new = r - (T)ev.logsum_cached(step) * P.w;
+            if (!not_finite(f_new) && f_new <= f_cur - c_ls * step * dd) {
+                PMF_EW x[i] = trial[i];
+                accepted = true;
+                break;
+            }
+            nfeval++;
+            if (nfeval >= maxnfeval) return;
+            step *= decr;
+        }
+        if (accepted) { ev.advance_cached(step); p_fresh = false; }
+        f_cur = f_new;
+        gprev_sq = ev.dot(g, g);
+        PMF_EW { gp[i] = g[i]; dp[i] = d[i]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Truncated Newton, lower bound 0                                 ref: src/tnc.c
 // ------------------------------------------------------------------------------------------------

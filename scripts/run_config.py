@@ -56,21 +56,20 @@ def main():
     t_up = time.time() - t0
     p = s.make_params(method, l2, maxupd=maxupd, limit_step=True, early_stop=False, reuse_prev=(method == "tncg"))
     step = 1e-7
-    import torch
     for _ in range(a.warmup):
         step = s.sweep(p, step)
-    torch.cuda.synchronize()
+    s.kernel_time(0)  # synchronises the session stream
     s.profile(True)
     t0 = time.time()
     for _ in range(a.sweeps - 0):
         if _ == a.sweeps - 1:
-            torch.cuda.synchronize(); tl = time.time()
+            s.kernel_time(0); tl = time.time()
             prevA, prevB = s.get_factors()
             tl = time.time() - tl
             t0 += tl
             step_last = step
         step = s.sweep(p, step)
-    torch.cuda.synchronize()
+    s.kernel_time(0)
     dt = (time.time() - t0) / a.sweeps
     kms = [s.kernel_time(w) for w in (0, 1)]
     A1, B1 = s.get_factors()
