@@ -50,6 +50,9 @@ __global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RowEval<T, NC, SL> ev;
+#ifdef PMF_TIMING
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
     ev.init(a.geom, a.F, smem);
     const int k = a.geom.k;
     T bs[NC];
@@ -104,6 +107,11 @@ __global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
         }
         ev.store_vec(out, x);
     }
+#ifdef PMF_TIMING
+    ev.tacc[5] = __builtin_amdgcn_s_memtime() - t_kernel;
+    if (ev.lane == 0)
+        for (int q = 0; q < 6; q++) atomicAdd(&g_pmf_timing[q], ev.tacc[q]);
+#endif
 }
 
 // ---- column sums of a dense [n x k] factor: sum_by_cols, ref: src/poismf.c:77-83 ---------------------
@@ -421,6 +429,17 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
 real_t* poismf_hip_session_A(poismf_hip_session* s) { return s->dA; }
 real_t* poismf_hip_session_B(poismf_hip_session* s) { return s->dB; }
 size_t poismf_hip_session_nnz(poismf_hip_session* s, int which) { return s->half[which ? 1 : 0].nnz; }
+
+#ifdef PMF_TIMING
+// development-only export (not in the header): read and reset the phase timers
+__attribute__((visibility("default"))) void poismf_hip_debug_timing(unsigned long long* out)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pmf_timing), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pmf_timing), z, sizeof(z));
+}
+#endif
 
 int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, const real_t* B_host)
 {

@@ -27,6 +27,17 @@
 
 namespace pmf {
 
+// Optional phase timers (build with -DPMF_TIMING): per-wave shader-clock totals of the phases of row_eval,
+// added to a global array at kernel exit.  Slots: 0 gather, 1 phase 1, 2 coef/div, 3 phase 2, 4 combine, 5 whole kernel.
+#ifdef PMF_TIMING
+__device__ unsigned long long g_pmf_timing[8];
+#define PMF_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define PMF_T1(slot, v) tacc[slot] += __builtin_amdgcn_s_memtime() - v
+#else
+#define PMF_T0(v)
+#define PMF_T1(slot, v)
+#endif
+
 template <class T> struct Slot;
 template <> struct Slot<float> {
     static constexpr int N = 4;
@@ -96,6 +107,9 @@ template <class T, int NC, int SL = 0> struct RowEval {
     const unsigned* ind;
     const T* val;
     unsigned nnz;
+#ifdef PMF_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
@@ -207,6 +221,7 @@ template <class T, int NC, int SL = 0> struct RowEval {
     // Gather chunk [c0, c0+cn) of the current row: indices and values, then the factor rows.
     __device__ __forceinline__ void load_chunk(unsigned c0, int cn)
     {
+        PMF_T0(tg);
         for (int j = lane; j < cn; j += WAVE) {
             idxb[j] = ind[c0 + j];
             xb[j] = val[c0 + j];
@@ -222,6 +237,7 @@ template <class T, int NC, int SL = 0> struct RowEval {
         else if (rem > WAVE) gather_batch<2>(q0, Q, j, t);
         else if (rem > 0) gather_batch<1>(q0, Q, j, t);
         wave_lds_fence();
+        PMF_T1(0, tg);
     }
 
     __device__ __forceinline__ void begin_row(const unsigned* ind_, const T* val_, unsigned nnz_)
@@ -374,7 +390,10 @@ template <class T, int NC, int SL = 0> struct RowEval {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
             if (!resident) load_chunk(c0, cn);
             for (int jb = 0; jb < cn; jb += WAVE) {
+                PMF_T0(t1);
                 const T pred = pred_lane(jb, cn);
+                PMF_T1(1, t1);
+                PMF_T0(t2);
                 const bool on = jb + lane < cn;
                 const T xj = xb[on ? jb + lane : 0];
                 if (store != nullptr && on) store[c0 + jb + lane] = pred;
@@ -383,11 +402,16 @@ template <class T, int NC, int SL = 0> struct RowEval {
                     wave_lds_fence();  // previous sub-chunk's readers of coefb are done
                     coefb[coef_slot(lane)] = on ? sgn * xj / pred : (T)0;
                     wave_lds_fence();
+                    PMF_T1(2, t2);
+                    PMF_T0(t3);
                     accumulate<false>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
+                    PMF_T1(3, t3);
                 }
             }
         }
+        PMF_T0(t4);
         if constexpr (WANT_G) combine_groups(part, acc);
+        PMF_T1(4, t4);
         if (store != nullptr) wave_lds_fence();
         if constexpr (WANT_F) return wave_sum(lpart);
         else return 0.0;
