@@ -46,9 +46,10 @@ def algorithmic_bytes_half(nnz, dimM, k, s):
     return nnz * (4 + s + k * s) + 2 * dimM * k * s + (dimM + 1) * 8
 
 
-def build_inputs(rank, world, use_float):
-    """Returns (csr, csc, dimA, dimB, rangesA, rangesB, nnz_total_local_csr) with only this rank's shards
-    populated in the whole-matrix-shaped CSR / CSC arrays the C-ABI takes."""
+def build_inputs(rank, world, use_float, BLOCK_ROWS=BLOCK_ROWS, DIMB=DIMB, BLOCK_NNZ=BLOCK_NNZ):
+    """Returns (csr, csc, dimA, dimB, rangesA, rangesB) with only this rank's shards populated in the
+    whole-matrix-shaped CSR / CSC arrays the C-ABI takes (tests/test_bench_inputs.py checks that the shards of all
+    ranks tile the CSR / CSC of the stacked blocks exactly)."""
     dt = np.float32 if use_float else np.float64
     dimA, dimB = BLOCK_ROWS * world, DIMB
     rangesA = [(r * BLOCK_ROWS, (r + 1) * BLOCK_ROWS) for r in range(world)]
@@ -82,20 +83,21 @@ def build_inputs(rank, world, use_float):
 
 
 def timed_sweeps(alt, steps, warmup, world, device):
+    multi = dist.is_initialized()
     for _ in range(warmup):
         alt.sweep()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         alt.sweep()
     torch.cuda.synchronize(device)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -178,9 +180,15 @@ def main():
     build.build()
     device = local_rank if world > 1 else 0
     torch.cuda.set_device(device)
-    if world > 1:
+    force_dist = os.environ.get("POISMF_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path on a single GPU (testing)
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"))
+        if force_dist and "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{device}"))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"))
 
     use_float = not a.fp64
     s = 4 if use_float else 8
@@ -192,7 +200,7 @@ def main():
     tot = torch.tensor([float(nnz_csr_local), res["kernel_ms"][0][0], res["kernel_ms"][1][0]], dtype=torch.float64,
                        device=f"cuda:{device}")
     kmax = tot.clone()
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     nnz_total = int(tot[0].item())
@@ -245,7 +253,7 @@ def main():
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(csr, csc, dimA, dimB, a.method, use_float, a.maxupd)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -14,6 +14,8 @@ The per-rank compute is a *backend* with three methods::
 
 The product backend is HipBackend (the C-ABI session, no fallback).  Tests inject their own.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -52,7 +54,7 @@ def exchange_shards(full, ranges, rank, group=None):
     """All-gather: on return every rank's `full` ([dim x k], replicated) holds every rank's row range.
     Equal ranges -> one in-place all_gather_into_tensor; otherwise one broadcast per owner."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and os.environ.get("POISMF_BENCH_FORCE_DIST") != "1":
         return
     sizes = {e - b for b, e in ranges}
     if len(sizes) == 1 and ranges[0][0] == 0 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)):
