@@ -204,6 +204,7 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     nnz_total = int(tot[0].item())
+    final_line = None
     if rank == 0:
         sec = res["seconds"]
         # roofline of the dominant kernel (half_sweep_kernel), this rank's launches: algorithmic bytes of the
@@ -252,10 +253,13 @@ def main():
             out["extra"] = extra
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(csr, csc, dimA, dimB, a.method, use_float, a.maxupd)
-        print(json.dumps(out))
+        final_line = json.dumps(out)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(final_line, flush=True)  # the one JSON line, after RCCL has printed whatever it prints
 
 
 if __name__ == "__main__":
