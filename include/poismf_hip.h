@@ -63,6 +63,24 @@ POISMF_HIP_API int run_poismf(
     const bool handle_interrupt, const int nthreads);
 
 /* ---------------------------------------------------------------------------------------------
+ * 1b. Factors for new rows with B fixed.
+ *
+ * Replaces: factors_multiple, ref: src/poismf.h:270-280 (prototype), src/pred.c:66-199 (body); called by the
+ * Python transform() through poismf_c_wrapper.pxi:147-199.  Same name, argument order and meaning: A [dimA x k]
+ * is output only (host), B / Bsum (with l1 already added) / Amean come from the fitted model, Xr* is the CSR of
+ * the new rows.  It is one half-sweep of the same row kernels with the column sums supplied by the caller.
+ * Returns 0, or 1 when out of memory / no device.
+ * ------------------------------------------------------------------------------------------- */
+POISMF_HIP_API int factors_multiple(
+    real_t *A, real_t *B, real_t *Bsum, real_t *Amean,
+    real_t *Xr, sparse_ix *Xr_indptr, sparse_ix *Xr_indices,
+    int k, size_t dimA,
+    real_t l2_reg, real_t w_mult,
+    real_t step_size, size_t niter, size_t maxupd,
+    int method, bool limit_step, bool reuse_mean,
+    int nthreads);
+
+/* ---------------------------------------------------------------------------------------------
  * 2. Device-resident session: the same path with X, A and B kept in HBM between calls, one
  *    half-sweep per call.  This is what bench.py times (inputs already resident) and what the
  *    one-process-per-GPU driver uses: each rank owns a contiguous range of A rows and of B rows,

@@ -81,6 +81,8 @@ class Oracle(_Lib):
         L.oracle_tncg_iteration.restype = i
         L.oracle_run_poismf.argtypes = [vp] * 8 + [sz] * 3 + [r] * 4 + [i, C.c_bool, sz, sz] + [C.c_bool] * 3 + [i]
         L.oracle_run_poismf.restype = i
+        L.oracle_factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
+        L.oracle_factors_multiple.restype = i
 
     # ---- G1 primitives -------------------------------------------------------------------
     def calc_grad_pgd(self, a, F, xval, xind):
@@ -157,6 +159,20 @@ class Oracle(_Lib):
             bool(handle_interrupt), nthreads)
 
 
+    _fm_symbol = "oracle_factors_multiple"
+
+    def factors_multiple(self, B, Bsum, Amean, Xr, Xr_indptr, Xr_indices, l2_reg, w_mult, step_size, niter, maxupd,
+                         method, limit_step, reuse_mean, nthreads=1):
+        """ref: src/pred.c:66-199; argument meaning of poismf_c_wrapper.pxi:147-160.  Returns A [n_new x k]."""
+        dimA, k = len(Xr_indptr) - 1, B.shape[1]
+        A = np.full((dimA, k), np.nan, self.np_t)  # the reference hands an uninitialised array
+        fn = getattr(self.lib, self._fm_symbol)
+        rc = fn(_p(A), _p(B), _p(Bsum), _p(Amean), _p(Xr), _p(Xr_indptr), _p(Xr_indices), k, dimA, l2_reg, w_mult,
+                step_size, niter, maxupd, METHOD[method], bool(limit_step), bool(reuse_mean), nthreads)
+        assert rc == 0
+        return A
+
+
 class _FData(C.Structure):
     pass
 
@@ -207,6 +223,8 @@ class Reference(_Lib):
         L.tncg_iteration.restype = None
         L.run_poismf.argtypes = [vp] * 8 + [sz] * 3 + [r] * 4 + [i, C.c_bool, sz, sz] + [C.c_bool] * 3 + [i]
         L.run_poismf.restype = i
+        L.factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
+        L.factors_multiple.restype = i
 
     def _fd(self, F, bsum, xval, xind, l2, w):
         return self.FData(F.ctypes.data, bsum.ctypes.data, xval.ctypes.data, xind.ctypes.data, len(xval),
@@ -312,3 +330,16 @@ class Reference(_Lib):
             A.shape[0], B.shape[0], A.shape[1], l2_reg, l1_reg, w_mult, step_size, METHOD[method],
             bool(limit_step), numiter, maxupd, bool(early_stop), bool(reuse_prev),
             bool(handle_interrupt), nthreads)
+
+    _fm_symbol = "factors_multiple"
+
+    def factors_multiple(self, B, Bsum, Amean, Xr, Xr_indptr, Xr_indices, l2_reg, w_mult, step_size, niter, maxupd,
+                         method, limit_step, reuse_mean, nthreads=1):
+        """ref: src/pred.c:66-199; argument meaning of poismf_c_wrapper.pxi:147-160.  Returns A [n_new x k]."""
+        dimA, k = len(Xr_indptr) - 1, B.shape[1]
+        A = np.full((dimA, k), np.nan, self.np_t)  # the reference hands an uninitialised array
+        fn = getattr(self.lib, self._fm_symbol)
+        rc = fn(_p(A), _p(B), _p(Bsum), _p(Amean), _p(Xr), _p(Xr_indptr), _p(Xr_indices), k, dimA, l2_reg, w_mult,
+                step_size, niter, maxupd, METHOD[method], bool(limit_step), bool(reuse_mean), nthreads)
+        assert rc == 0
+        return A

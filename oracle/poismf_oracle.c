@@ -1213,3 +1213,55 @@ ORC_API int oracle_run_poismf(real_t *A, real_t *Xr, sparse_ix *Xr_indptr, spars
     free(bsum_w);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Factors for new rows with B fixed                    ref: src/pred.c:66-199 (factors_multiple) */
+/* ------------------------------------------------------------------------------------------ */
+/* `Bsum` arrives with l1 already added (ref: :80).  Quirks restated: (i) rows start at Amean unless the
+   solver is TNCG without reuse_mean, which starts them at 1e-3 inside tncg_iteration (ref: :144-147);
+   (ii) PG rescales Bsum by -step on every inner iteration and halves the step (ref: :152-167); with
+   w_mult != 1 the per-row Bsum_w was already scaled once by -step at set-up (ref: :121-122), so it ends up
+   scaled twice; (iii) CG runs ONE cg_iteration with maxiter = maxupd * niter (ref: :175-178). */
+ORC_API int oracle_factors_multiple(real_t *A, real_t *B, real_t *Bsum, real_t *Amean, real_t *Xr,
+                                    sparse_ix *Xr_indptr, sparse_ix *Xr_indices, int k, size_t dimA,
+                                    real_t l2_reg, real_t w_mult, real_t step_size, size_t niter,
+                                    size_t maxupd, int method, bool limit_step, bool reuse_mean, int nthreads)
+{
+    const size_t ks = (size_t)k;
+    real_t *bsum_w = NULL, *bsum_w_scaled = NULL, *bsum_scaled = NULL;
+    if (method == M_PG) {
+        if (w_mult == 1.) bsum_scaled = (real_t *)malloc(sizeof(real_t) * ks);
+        else bsum_w_scaled = (real_t *)malloc(sizeof(real_t) * ks * dimA);
+    }
+    if (w_mult != 1.) {
+        bsum_w = (real_t *)malloc(sizeof(real_t) * ks * dimA);
+        oracle_adjustment_bsum(B, Bsum, bsum_w, Xr_indices, Xr_indptr, dimA, ks, w_mult, nthreads);
+        if (method == M_PG) for (size_t i = 0; i < dimA * ks; i++) bsum_w[i] *= -step_size;
+    }
+    if (reuse_mean || method != M_TNCG)
+        for (size_t r = 0; r < dimA; r++) memcpy(A + r * ks, Amean, sizeof(real_t) * ks);
+
+    if (method == M_PG) {
+        for (size_t it = 0; it < niter; it++) {
+            if (w_mult == 1.) {
+                memcpy(bsum_scaled, Bsum, sizeof(real_t) * ks);
+                vscal(k, -step_size, bsum_scaled);
+            } else {
+                memcpy(bsum_w_scaled, bsum_w, sizeof(real_t) * ks * dimA);
+                for (size_t i = 0; i < dimA * ks; i++) bsum_w_scaled[i] *= -step_size;
+            }
+            real_t cnst_div = 1. / (1. + 2. * l2_reg * step_size);
+            oracle_pg_iteration(A, B, Xr, Xr_indptr, Xr_indices, dimA, ks, cnst_div, bsum_scaled,
+                                bsum_w_scaled, step_size, w_mult, maxupd, nthreads);
+            step_size *= 0.5;
+        }
+    } else if (method == M_CG) {
+        oracle_cg_iteration(A, B, Xr, Xr_indptr, Xr_indices, dimA, ks, limit_step, Bsum, l2_reg, w_mult,
+                            maxupd * niter, bsum_w, nthreads);
+    } else {
+        oracle_tncg_iteration(A, B, reuse_mean, Xr, Xr_indptr, Xr_indices, dimA, ks, Bsum, l2_reg, w_mult,
+                              (int)maxupd, 0, bsum_w, nthreads);
+    }
+    free(bsum_w); free(bsum_w_scaled); free(bsum_scaled);
+    return 0;
+}

@@ -38,7 +38,7 @@ def _params_type(c_real):
 
 # every symbol include/poismf_hip.h declares
 EXPORTED_SYMBOLS = (
-    "run_poismf", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
+    "run_poismf", "factors_multiple", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
     "poismf_hip_session_B", "poismf_hip_session_set_factors", "poismf_hip_session_get_factors",
     "poismf_hip_half_sweep", "poismf_hip_session_profile", "poismf_hip_session_kernel_time",
     "poismf_hip_session_nnz",
@@ -59,6 +59,8 @@ def load_library(use_float):
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     lib.run_poismf.argtypes = [vp] * 8 + [sz] * 3 + [r] * 4 + [i, C.c_bool, sz, sz] + [C.c_bool] * 3 + [i]
     lib.run_poismf.restype = i
+    lib.factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
+    lib.factors_multiple.restype = i
     lib.poismf_hip_session_create.argtypes = [C.POINTER(vp), i, vp] + [vp] * 6 + [sz] * 3 + [sz] * 4
     lib.poismf_hip_session_create.restype = i
     lib.poismf_hip_session_destroy.argtypes = [vp]
@@ -123,6 +125,25 @@ def _run_poismf(Xr, Xr_indices, Xr_indptr, Xc, Xc_indices, Xc_indptr, A, B, meth
     return ret
 
 
+def _predict_factors_multiple(B, Bsum, Amean, Xr_indptr, Xr_indices, Xr, l2_reg=1e9, w_mult=1., step_size=1e-7,
+                              niter=10, maxupd=1, method="tncg", limit_step=0, reuse_mean=1, nthreads=1):
+    """Drop-in for c_funs_{float,double}._predict_factors_multiple (ref: poismf/poismf_c_wrapper.pxi:147-199):
+    same positional order and defaults; returns the new factors A [n_new x k]."""
+    use_float = B.dtype == np.float32
+    _check_arrays(use_float, (B, Bsum, Amean, Xr), (Xr_indptr, Xr_indices))
+    lib = load_library(use_float)
+    k = B.shape[1]
+    dimA = Xr_indptr.shape[0] - 1
+    A = np.empty((dimA, k), dtype=B.dtype)
+    ret = lib.factors_multiple(_ptr(A), _ptr(B), _ptr(Bsum), _ptr(Amean), _ptr(Xr) if Xr.shape[0] else None, _ptr(Xr_indptr),
+                               _ptr(Xr_indices) if Xr_indices.shape[0] else None, k, dimA, l2_reg, w_mult, step_size,
+                               int(niter), int(maxupd), _METHOD.get(method, 1), bool(limit_step), bool(reuse_mean),
+                               int(nthreads))
+    if ret:
+        raise MemoryError("Could not allocate enough memory.")                      # ref: pxi:205-206
+    return A
+
+
 class PoisMF:
     """Fit-path subset of the reference's PoisMF (ref: poismf/__init__.py:205-495).  Only what sits on
     the factor-update path is mirrored: constructor arguments that reach run_poismf, ``fit`` for SciPy
@@ -172,6 +193,22 @@ class PoisMF:
                     self.nthreads_)
         self.Bsum = self.B.sum(axis=0) + self.l1_reg_
         self.Amean = self.A.mean(axis=0)
+
+
+def _transform(self, X):
+    """Factors for new rows given as a SciPy CSR / COO matrix (ref: poismf/__init__.py:619-692, transform)."""
+    import scipy.sparse as sp
+    assert self.is_fitted and X.shape[0] > 0
+    csr = sp.csr_matrix(X)
+    csr.sum_duplicates(); csr.sort_indices()
+    dt = np.float32 if self.use_float else np.float64
+    return _predict_factors_multiple(
+        self.B, self.Bsum.astype(dt), self.Amean.astype(dt), csr.indptr.astype(np.uint64), csr.indices.astype(np.uint64),
+        csr.data.astype(dt), self.l2_reg_, self.weight_mult, self.initial_step, self.niter_, self.maxupd_, self.method,
+        self.limit_step, self.reuse_prev, self.nthreads_)
+
+
+PoisMF.transform = _transform
 
 
 class _DevArray:

@@ -404,7 +404,8 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
     if (hipMalloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t)) != hipSuccess) return fail();
     if (hipMalloc(&s->d_counter, sizeof(unsigned)) != hipSuccess) return fail();
     // half 0 updates B: rows of the CSC; half 1 updates A: rows of the CSR
-    if (build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, rowB_begin, rowB_end)) return fail();
+    if (Xc_indptr != nullptr &&
+        build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, rowB_begin, rowB_end)) return fail();
     if (build_half(s->half[1], s->stream, Xr, Xr_indptr, Xr_indices, dimA, dimB, rowA_begin, rowA_end)) return fail();
     *out = s;
     return 0;
@@ -484,8 +485,10 @@ int poismf_hip_session_kernel_time(poismf_hip_session* s, int which, double* tot
     return 0;
 }
 
-int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_params* p, real_t step_size, real_t cnst_div,
-                          size_t* n_unchanged)
+// bsum_override != nullptr: use this HOST k-vector (already carrying l1 and any PG scaling) instead of the column
+// sums of the fixed factor; neg_step_override then replaces -step_size as the PG scale of the per-row Bsum_w.
+static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_params* p, real_t step_size, real_t cnst_div,
+                           size_t* n_unchanged, const real_t* bsum_override, real_t neg_step_override)
 {
     HIP_TRY(hipSetDevice(s->device));
     which = which ? 1 : 0;
@@ -499,10 +502,16 @@ int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_par
     // column sums of the fixed factor (+ l1), with the PG pre-scaling when w == 1:
     //   B half: * (-step)            ref: src/poismf.c:523-524
     //   A half: * (-step) twice      ref: src/poismf.c:573-577 (quirk Q1)
-    const real_t neg_step = -step_size;
-    int nscale = 0;
-    if (is_pg && !weighted) nscale = which ? 2 : 1;
-    if (colsum(s, F, dimF, p->l1_reg, neg_step, nscale)) return 1;
+    real_t neg_step = -step_size;
+    if (bsum_override != nullptr) {
+        neg_step = neg_step_override;
+        HIP_TRY(hipMemcpyAsync(s->d_bsum, bsum_override, s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));  // the caller's host vector may change right after this call
+    } else {
+        int nscale = 0;
+        if (is_pg && !weighted) nscale = which ? 2 : 1;
+        if (colsum(s, F, dimF, p->l1_reg, neg_step, nscale)) return 1;
+    }
 
     HalfArgs<real_t> a;
     a.M = M; a.F = F;
@@ -573,6 +582,12 @@ int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_par
         *n_unchanged = cnt;
     }
     return 0;
+}
+
+int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_params* p, real_t step_size, real_t cnst_div,
+                          size_t* n_unchanged)
+{
+    return half_sweep_impl(s, which, p, step_size, cnst_div, n_unchanged, nullptr, (real_t)0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -669,6 +684,65 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
         if (stopped && !handle_interrupt) raise(SIGINT);
     }
     return ret_code;
+}
+
+// -------------------------------------------------------------------------------------------------
+// factors_multiple: latent factors of new rows with B fixed          ref: src/pred.c:66-199
+// -------------------------------------------------------------------------------------------------
+int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* Xr, sparse_ix* Xr_indptr,
+                     sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, real_t step_size,
+                     size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean, int nthreads)
+{
+    (void)nthreads;
+    const size_t ks = (size_t)k;
+    const size_t nnz = Xr_indptr[dimA];
+    // rows start at the mean of the fitted A, except TNCG without reuse_mean (1e-3, set in the kernel); ref: :144-147
+    if (reuse_mean || method != POISMF_TNCG)
+        for (size_t r = 0; r < dimA; r++) memcpy(A + r * ks, Amean, ks * sizeof(real_t));
+    if (nnz == 0) {  // every row is empty: all three drivers zero such rows (quirk Q7)
+        memset(A, 0, dimA * ks * sizeof(real_t));
+        return 0;
+    }
+    size_t dimB = 0;  // the reference never needs the number of items; the device copy of B needs the rows in use
+    for (size_t i = 0; i < nnz; i++) dimB = std::max(dimB, (size_t)Xr_indices[i] + 1);
+
+    int device = 0;
+    if (const char* e = getenv("POISMF_HIP_DEVICE")) device = atoi(e);
+    poismf_hip_session* s = nullptr;
+    int rc = 0;
+    std::vector<real_t> bs(ks);
+    if (poismf_hip_session_create(&s, device, nullptr, Xr, Xr_indptr, Xr_indices, nullptr, nullptr, nullptr, dimA, dimB, ks, 0,
+                                  dimA, 0, 0) ||
+        hipMemcpy(s->dA, A, dimA * ks * sizeof(real_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s->dB, B, dimB * ks * sizeof(real_t), hipMemcpyHostToDevice) != hipSuccess) {
+        rc = 1;
+    } else {
+        poismf_hip_params p;
+        p.l2_reg = l2_reg; p.l1_reg = 0; p.w_mult = w_mult; p.step_size = step_size;
+        p.method = method; p.limit_step = limit_step; p.maxupd = maxupd;
+        p.early_stop = 0; p.reuse_prev = reuse_mean;
+        const bool weighted = w_mult != (real_t)1.;
+        if (method == POISMF_PG) {                                    // ref: :152-169
+            const real_t step0 = step_size;
+            for (size_t it = 0; it < niter && !rc; it++) {
+                for (size_t c = 0; c < ks; c++) bs[c] = weighted ? Bsum[c] : Bsum[c] * (-step_size);
+                const real_t cnst_div = 1. / (1. + 2. * l2_reg * step_size);
+                // w != 1: Bsum_w was scaled by -step at set-up (ref: :121-122) and again by -step here (ref: :162)
+                rc = half_sweep_impl(s, 1, &p, step_size, cnst_div, nullptr, bs.data(), (-step0) * (-step_size));
+                step_size *= 0.5;
+            }
+        } else {
+            for (size_t c = 0; c < ks; c++) bs[c] = Bsum[c];
+            if (method == POISMF_CG) p.maxupd = maxupd * niter;      // ref: :175-178
+            rc = half_sweep_impl(s, 1, &p, step_size, (real_t)1, nullptr, bs.data(), -step_size);
+        }
+        if (!rc && (hipStreamSynchronize(s->stream) != hipSuccess ||
+                    hipMemcpy(A, s->dA, dimA * ks * sizeof(real_t), hipMemcpyDeviceToHost) != hipSuccess))
+            rc = 1;
+    }
+    poismf_hip_session_destroy(s);
+    if (rc) fprintf(stderr, "Error: out of memory.\n");
+    return rc ? 1 : 0;
 }
 
 }  // extern "C"

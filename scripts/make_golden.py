@@ -109,6 +109,24 @@ def full_fixture(ref, is_float):
     return d
 
 
+def factors_fixture(ref, is_float):
+    """factors_multiple (ref src/pred.c:66-199) on the edge matrix, fitted-model inputs synthesised."""
+    d = {}
+    csr, csc, A0, B0 = H.small_problem(60, 90, 900, 8, is_float, seed=3, empty_rows=(0, 17, 59), empty_cols=(5, 89),
+                                       powerlaw=True)
+    Bsum = (B0.astype(np.float64).sum(0) + 0.25).astype(B0.dtype)
+    Amean = A0.mean(0).astype(B0.dtype)
+    d.update({"csr_data": csr[0], "csr_indices": csr[1].astype(np.int32), "csr_indptr": csr[2].astype(np.int32),
+              "B": B0, "Bsum": Bsum, "Amean": Amean})
+    for method in ("pg", "cg", "tncg"):
+        l2, maxupd, _ = harness.auto_defaults(method, 8)
+        for w in (1.0, 3.0):
+            for reuse in (True, False):
+                d[f"{method}_w{int(w)}_r{int(reuse)}"] = ref.factors_multiple(B0, Bsum, Amean, csr[0], csr[2], csr[1], l2, w,
+                                                                             1e-7, 3, maxupd, method, True, reuse)
+    return d
+
+
 def main():
     bindings.build(ref=True)
     os.makedirs(OUT, exist_ok=True)
@@ -117,6 +135,7 @@ def main():
         tag = "f32" if is_float else "f64"
         np.savez_compressed(os.path.join(OUT, f"rows_{tag}.npz"), **rows_fixture(ref, is_float))
         np.savez_compressed(os.path.join(OUT, f"full_{tag}.npz"), **full_fixture(ref, is_float))
+        np.savez_compressed(os.path.join(OUT, f"factors_{tag}.npz"), **factors_fixture(ref, is_float))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -239,3 +239,45 @@ def test_nonnegativity_and_zero_rows_at_scale(prec):
     A, B, args = gpu_run(csr, csc, A0, B0, "pg", 1, 50)
     Ar, Br = oracle_run(prec, csr, csc, A0, B0, "pg", args)
     compare(prec, "pg", csr, args, A, B, Ar, Br, False)
+
+
+# ------------------------------------------------------------------ N1: factors_multiple (new rows, B fixed)
+@pytest.mark.parametrize("method", ["pg", "cg", "tncg"])
+@pytest.mark.parametrize("w", [1.0, 3.0])
+@pytest.mark.parametrize("reuse", [True, False])
+def test_factors_multiple_vs_golden_and_oracle(prec, method, w, reuse):
+    """ref: src/pred.c:66-199 through the C-ABI symbol `factors_multiple` (Python mirror of pxi:147-199)"""
+    gold = np.load(os.path.join(GOLD, f"factors_{'f32' if prec else 'f64'}.npz"))
+    u = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+    data, indices, indptr = gold["csr_data"], u(gold["csr_indices"]), u(gold["csr_indptr"])
+    B, Bsum, Amean = gold["B"], gold["Bsum"], gold["Amean"]
+    l2, maxupd, _ = harness.auto_defaults(method, 8)
+    A = api._predict_factors_multiple(B, Bsum, Amean, indptr, indices, data, l2, w, 1e-7, 3, maxupd, method, True, reuse, 1)
+    Ao = bindings.Oracle(prec).factors_multiple(B, Bsum, Amean, data, indptr, indices, l2, w, 1e-7, 3, maxupd, method, True, reuse)
+    Ag = gold[f"{method}_w{int(w)}_r{int(reuse)}"]
+    assert not A[[0, 17, 59]].any()
+    for ref_arr in (Ao, Ag):
+        if method == "pg":
+            assert H.scaled_err(A, ref_arr) <= T(prec, 1e-12, 1e-5)
+        else:
+            l2o = l2 if method == "cg" else 0.0
+            fo = H.half_objective(A, B, data, indices, indptr, Bsum, l2o, w)
+            fr = H.half_objective(ref_arr, B, data, indices, indptr, Bsum, l2o, w)
+            assert abs(fo - fr) <= T(prec, 1e-6, 2e-2) * abs(fr)
+            if not prec and method == "cg":
+                assert H.scaled_err(A, ref_arr) <= 5e-3
+
+
+def test_transform_matches_fit_rows(prec):
+    """PoisMF.transform on the training rows with CG reproduces a CG A-half from Amean (same kernels, B fixed)"""
+    import scipy.sparse as sp
+    csr, csc, A0, B0 = H.small_problem(400, 300, 12000, 50, prec, seed=12)
+    X = sp.csr_matrix((csr[0], csr[1].astype(np.int64), csr[2].astype(np.int64)), shape=(400, 300))
+    m = api.PoisMF(k=50, method="cg", use_float=prec, niter=3).fit(X.tocoo())
+    An = m.transform(X)
+    assert An.shape == (400, 50) and np.isfinite(An).all() and (An >= 0).all()
+    Ao = bindings.Oracle(prec).factors_multiple(m.B, m.Bsum.astype(m.B.dtype), m.Amean.astype(m.B.dtype), csr[0], csr[2], csr[1],
+                                                m.l2_reg_, 1.0, 1e-7, m.niter_, m.maxupd_, "cg", True, False)
+    fo = H.half_objective(An, m.B, csr[0], csr[1], csr[2], m.Bsum, m.l2_reg_)
+    fr = H.half_objective(Ao, m.B, csr[0], csr[1], csr[2], m.Bsum, m.l2_reg_)
+    assert abs(fo - fr) <= T(prec, 1e-8, 1e-4) * abs(fr)

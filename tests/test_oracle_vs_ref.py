@@ -242,3 +242,27 @@ def test_threads_do_not_change_results(libs):
         a1, b1, _ = _run(orc, csr, csc, A0, B0, method, 2, nthreads=1)
         a4, b4, _ = _run(orc, csr, csc, A0, B0, method, 2, nthreads=4)
         assert np.array_equal(a1, a4) and np.array_equal(b1, b4)
+
+
+# ---------------------------------------------------------------- N1: factors_multiple
+@pytest.mark.parametrize("method", ["pg", "cg", "tncg"])
+@pytest.mark.parametrize("w", [1.0, 3.0])
+@pytest.mark.parametrize("reuse", [True, False])
+def test_factors_multiple(libs, method, w, reuse):
+    """ref: src/pred.c:66-199.  Bit-exact in the BLAS flavour; the portable flavour to the usual tolerances."""
+    orc, ref, is_float = libs
+    csr, csc, A0, B0 = H.small_problem(60, 90, 900, 8, is_float, seed=3, empty_rows=(0, 17), powerlaw=True)
+    Bsum = (B0.astype(np.float64).sum(0) + 0.25).astype(B0.dtype)
+    Amean = A0.mean(0).astype(B0.dtype)
+    l2, maxupd, _ = harness.auto_defaults(method, 8)
+    a = orc.factors_multiple(B0, Bsum, Amean, csr[0], csr[2], csr[1], l2, w, 1e-7, 3, maxupd, method, True, reuse)
+    b = ref.factors_multiple(B0, Bsum, Amean, csr[0], csr[2], csr[1], l2, w, 1e-7, 3, maxupd, method, True, reuse)
+    assert not a[[0, 17]].any() and not b[[0, 17]].any()
+    if _EXACT["on"]:
+        assert np.array_equal(a, b)
+    elif method == "pg":
+        assert H.scaled_err(a, b) <= tol(is_float, 1e-12, 1e-5)
+    else:
+        fo = H.half_objective(a, B0, csr[0], csr[1], csr[2], Bsum, l2 if method == "cg" else 0.0, w)
+        fr = H.half_objective(b, B0, csr[0], csr[1], csr[2], Bsum, l2 if method == "cg" else 0.0, w)
+        assert abs(fo - fr) <= tol(is_float, 1e-6, 2e-2) * abs(fr)
