@@ -39,17 +39,18 @@ template <class T> struct HalfArgs {
     RowParams<T> P;
     int reuse_prev, early_stop;
     unsigned* n_unchanged;
+    unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
 };
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
 
 // One wavefront (= one 64-thread workgroup, so no workgroup barrier is ever needed and the LDS tile
 // is private) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the nnz-sorted permutation.
-template <class T, int NC, int METHOD, int SL>
-__global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
+template <class T, int NC, int METHOD, int SL, int NW>
+__global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    RowEval<T, NC, SL> ev;
+    RowEval<T, NC, SL, NW> ev;
 #ifdef PMF_TIMING
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
 #endif
@@ -58,8 +59,31 @@ __global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
     T bs[NC];
     ev.load_vec(a.bsum, bs);
 
-    for (unsigned r = blockIdx.x; r < a.nrows; r += gridDim.x) {
-        const unsigned lrow = uniform(a.perm[a.perm_begin + r]);
+    // Row hand-out.  PG does the same work for every nonzero, so the nnz-sorted rows are dealt out statically
+    // (row r, r + grid, ...).  CG and TNCG take anything from a handful to ~400 evaluations per row: there rows are
+    // pulled from a device-wide counter in nnz-descending order (longest first -- the GPU form of the reference's
+    // `schedule(dynamic)`, ref: src/poismf.c:296, :352), one returning atomic per row.
+    unsigned r = blockIdx.x;
+    for (;;) {
+        if (a.queue != nullptr) {
+            if constexpr (NW > 1) {
+                // broadcast through the last 16 bytes of the DYNAMIC LDS block (a static __shared__ object
+                // would shift the dynamic base off 16-byte alignment and slow every ds_read_b128 down)
+                unsigned* next_row = (unsigned*)(smem + lds_bytes_per_block(a.geom, sizeof(T), NW) - 16);
+                if (threadIdx.x == 0) *next_row = atomicAdd(a.queue, 1u);
+                __syncthreads();
+                r = uniform(*next_row);
+                __syncthreads();
+            } else {
+                unsigned t = 0;
+                if (ev.lane == 0) t = atomicAdd(a.queue, 1u);
+                r = uniform(t);
+            }
+        }
+        if (r >= a.nrows) break;
+        const unsigned this_r = r;
+        r += gridDim.x;
+        const unsigned lrow = uniform(a.perm[a.perm_begin + this_r]);
         const unsigned long long p0 = a.indptr[lrow], p1 = a.indptr[lrow + 1];
         const unsigned nnz = uniform((unsigned)(p1 - p0));
         T* out = a.M + (size_t)(a.row_offset + lrow) * (size_t)k;
@@ -98,18 +122,18 @@ __global__ __launch_bounds__(WAVE) void half_sweep_kernel(const HalfArgs<T> a)
             T prev[NC];
             PMF_EW prev[i] = x[i];
             if (!a.reuse_prev) { PMF_EW x[i] = (T)1e-3; }                   // ref: src/poismf.c:379-381
-            (void)Tnc<T, NC, SL>::minimize(ev, a.P, shift, x);
+            (void)Tnc<T, NC, SL, NW>::minimize(ev, a.P, shift, x);
             if (a.early_stop) {                                             // ref: src/poismf.c:393-396
                 PMF_EW prev[i] = prev[i] - x[i];
                 const T moved = ev.dot(prev, prev);
-                if ((double)moved <= 1e-4 && ev.lane == 0) atomicAdd(a.n_unchanged, 1u);
+                if ((double)moved <= 1e-4 && ev.lane == 0 && ev.wid == 0) atomicAdd(a.n_unchanged, 1u);
             }
         }
         ev.store_vec(out, x);
     }
 #ifdef PMF_TIMING
     ev.tacc[5] = __builtin_amdgcn_s_memtime() - t_kernel;
-    if (ev.lane == 0)
+    if (ev.lane == 0 && ev.wid == 0)
         for (int q = 0; q < 6; q++) atomicAdd(&g_pmf_timing[q], ev.tacc[q]);
 #endif
 }
@@ -177,6 +201,7 @@ namespace {
 constexpr size_t LDS_PER_CU = 160 * 1024;
 constexpr size_t LDS_RESIDENT_LIMIT = 64 * 1024;  // largest tile a single wave may claim
 constexpr int NUM_CU = 256;
+constexpr int MAX_LAUNCHES = 64;  // row bins per half-sweep (16 fine classes + powers of two up to 2^31)
 
 struct Bin {
     unsigned begin, count;  // range of the nnz-sorted permutation
@@ -201,12 +226,16 @@ struct ProfRec { hipEvent_t t0, t1; int which; };
 struct poismf_hip_session {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipStream_t aux_stream = nullptr;  // long-row launches run here, next to the other bins
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t dimA = 0, dimB = 0, k = 0;
     real_t *dA = nullptr, *dB = nullptr;
     Half half[2];  // [0]: rows of B (CSC), [1]: rows of A (CSR)
     real_t* d_bsum = nullptr;
     real_t* d_partial = nullptr;
     unsigned* d_counter = nullptr;
+    unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     int colsum_waves = 1024;
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -311,28 +340,32 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_p
     return g;
 }
 
-template <int NC, int METHOD, int SL> int launch_bin(poismf_hip_session* s, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+template <int NC, int METHOD, int SL, int NW> int launch_bin(hipStream_t stream, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
 {
-    auto kern = half_sweep_kernel<real_t, NC, METHOD, SL>;
+    auto kern = half_sweep_kernel<real_t, NC, METHOD, SL, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)LDS_PER_CU));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), lds, s->stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW), lds, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <int NC, int SL> int launch_method(poismf_hip_session* s, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+template <int NC, int SL, int NW = 1> int launch_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
 {
     switch (method) {
-        case POISMF_PG: return launch_bin<NC, K_PG, SL>(s, a, lds, grid);
-        case POISMF_CG: return launch_bin<NC, K_CG, SL>(s, a, lds, grid);
-        default: return launch_bin<NC, K_TNCG, SL>(s, a, lds, grid);
+        case POISMF_PG: return launch_bin<NC, K_PG, SL, NW>(stream, a, lds, grid);
+        case POISMF_CG: return launch_bin<NC, K_CG, SL, NW>(stream, a, lds, grid);
+        default: return launch_bin<NC, K_TNCG, SL, NW>(stream, a, lds, grid);
     }
 }
+
+// Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
+constexpr unsigned LONG_ROW_NNZ = 8192;
+constexpr int LONG_NW = 8;
 
 // Slot counts with a compile-time specialisation: the k values of the BASELINE configs
 // (fp32: k = 49..52 -> 13 slots, k = 97..100 -> 25; fp64: k = 49..50 -> 25, k = 99..100 -> 50).
@@ -393,6 +426,10 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
     if (!s) return 1;
     s->device = device;
     s->stream = (hipStream_t)stream;
+    if (s->stream == nullptr) {  // no stream given: own one, so that fork / join with the auxiliary stream is explicit
+        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return 1; }
+        s->owns_stream = true;
+    }
     s->dimA = dimA; s->dimB = dimB; s->k = k;
     auto fail = [&]() { poismf_hip_session_destroy(s); return 1; };
     const size_t slack = 16;
@@ -403,6 +440,10 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
     if (hipMalloc(&s->d_bsum, k * sizeof(real_t) + slack) != hipSuccess) return fail();
     if (hipMalloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t)) != hipSuccess) return fail();
     if (hipMalloc(&s->d_counter, sizeof(unsigned)) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_queue, sizeof(unsigned) * MAX_LAUNCHES) != hipSuccess) return fail();
+    if (hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail();
+    if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) return fail();
+    if (hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail();
     // half 0 updates B: rows of the CSC; half 1 updates A: rows of the CSR
     if (Xc_indptr != nullptr &&
         build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, rowB_begin, rowB_end)) return fail();
@@ -416,7 +457,13 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipStreamSynchronize(s->stream);
+    if (s->aux_stream) (void)hipStreamSynchronize(s->aux_stream);
     for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
+    s->prof.clear();
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
+    if (s->owns_stream) (void)hipStreamDestroy(s->stream);
     free_half(s->half[0]);
     free_half(s->half[1]);
     if (s->dA) (void)hipFree(s->dA);
@@ -424,6 +471,7 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     if (s->d_bsum) (void)hipFree(s->d_bsum);
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->d_queue) (void)hipFree(s->d_queue);
     delete s;
 }
 
@@ -540,36 +588,85 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
     // solver) are merged into one launch.
-    struct Launch { unsigned begin, count; TileGeom geom; };
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; };
     std::vector<Launch> launches;
+    static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
+    unsigned long_thr = LONG_ROW_NNZ;
+    if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
     for (const Bin& b : h.bins) {
         TileGeom g = plan_geom(s->k, b.max_nnz, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) g.resident = 0;  // one pass: "gather once" and "stream" are the same thing
+        if (!no_long && b.max_nnz > long_thr) {
+            // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
+            // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
+            g.resident = 0;
+            g.pq_cap = 0;
+            int cap = 128;
+            for (;;) {
+                g.cap = cap;
+                if (cap <= 16 || lds_bytes_per_block(g, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
+                cap -= 16;
+            }
+            if (!launches.empty() && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
+                launches.back().count += b.count;
+            else
+                launches.push_back({ b.begin, b.count, g, LONG_NW });
+            continue;
+        }
         if (!launches.empty() && launches.back().geom.cap == g.cap && launches.back().geom.resident == g.resident &&
-            (g.resident == 0) && g.pq_cap == 0 && launches.back().geom.pq_cap == 0 &&
+            (g.resident == 0) && g.pq_cap == 0 && launches.back().geom.pq_cap == 0 && launches.back().nw == 1 &&
             launches.back().begin + launches.back().count == b.begin)
             launches.back().count += b.count;
         else
-            launches.push_back({ b.begin, b.count, g });
+            launches.push_back({ b.begin, b.count, g, 1 });
     }
+    static const bool static_rows = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;  // testing knob
+    const bool dynamic = !is_pg && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
+    if (dynamic) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
+    // the few workgroup-per-row launches of the power-law tail occupy a few dozen CUs for a long time: run them on a
+    // second stream beside the other bins (fork after the column sums, join before anything reads the result)
+    static const bool no_fork = getenv("POISMF_HIP_NO_FORK") != nullptr;  // testing knob
+    bool forked = false;
+    for (const Launch& L : launches) forked = forked || L.nw > 1;
+    forked = forked && !no_fork;
+    hipStream_t long_stream = forked ? s->aux_stream : s->stream;
+    if (forked) {
+        HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
+    }
+    int launch_no = 0;
     for (const Launch& L : launches) {
+        a.queue = dynamic ? s->d_queue + launch_no : nullptr;
+        launch_no++;
         a.perm_begin = L.begin;
         a.nrows = L.count;
         a.geom = L.geom;
-        const size_t lds = lds_bytes_per_wave(a.geom, sizeof(real_t));
+        const size_t lds = lds_bytes_per_block(a.geom, sizeof(real_t), L.nw);
         const unsigned waves_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / lds));
         unsigned grid_mult = 2;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)NUM_CU * waves_per_cu * grid_mult);
         int rc = 1;
+        if (L.nw > 1) {
+            switch (slots_per_lane(s->k)) {
+                case 1: rc = launch_method<1 * SLOT_ELEMS, 0, LONG_NW>(long_stream, p->method, a, lds, grid); break;
+                case 2: rc = launch_method<2 * SLOT_ELEMS, 0, LONG_NW>(long_stream, p->method, a, lds, grid); break;
+            }
+            if (rc) return 1;
+            continue;
+        }
         static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
-        if (!generic_only && a.geom.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A>(s, p->method, a, lds, grid);
-        else if (!generic_only && a.geom.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B>(s, p->method, a, lds, grid);
+        if (!generic_only && a.geom.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A>(s->stream, p->method, a, lds, grid);
+        else if (!generic_only && a.geom.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B>(s->stream, p->method, a, lds, grid);
         else switch (slots_per_lane(s->k)) {
-            case 1: rc = launch_method<1 * SLOT_ELEMS, 0>(s, p->method, a, lds, grid); break;
-            case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(s, p->method, a, lds, grid); break;
+            case 1: rc = launch_method<1 * SLOT_ELEMS, 0>(s->stream, p->method, a, lds, grid); break;
+            case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(s->stream, p->method, a, lds, grid); break;
         }
         if (rc) return 1;
+    }
+    if (forked) {
+        HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
     }
     if (s->profiling) {
         HIP_TRY(hipEventRecord(rec.t1, s->stream));

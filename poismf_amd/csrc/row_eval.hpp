@@ -72,12 +72,25 @@ __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t s
     return b;
 }
 
+__host__ __device__ inline size_t lds_bytes_per_block(const TileGeom& g, size_t sizeof_real, int nw)
+{
+    size_t b = (size_t)nw * lds_bytes_per_wave(g, sizeof_real);
+    if (nw > 1) b += 16 * (((size_t)nw * sizeof(double) + 15) / 16) + (size_t)nw * g.s_load * 16 + 16;  // + row-queue broadcast word
+    return b;
+}
+
 // NC = elements per lane = slots per lane (NS) x elements per slot.
 // SL > 0 fixes the number of 16-byte slots per factor row at compile time (specialisations for the k values of
 // the BASELINE configs): the row stride, group size and every LDS offset of the two phases then fold into
 // instruction immediates, which removes most of the address arithmetic (measured: 85 % of the issued
 // instructions of the generic phase-2 loop were address / mask bookkeeping).  SL = 0 is the generic kernel.
-template <class T, int NC, int SL = 0> struct RowEval {
+// NW > 1: NW wavefronts (one workgroup) cooperate on ONE row -- the long-row path for the power-law tail.  Every
+// wave keeps its own full copy of the solver state and runs the same wave-uniform control flow; inside an
+// evaluation wave w streams chunks w, w + NW, ... of the row through its private LDS tile, and the NW partial
+// results are combined through LDS in a fixed order behind a workgroup barrier, so all copies stay bit-identical.
+// What it buys is memory-level parallelism: one wave keeps ~8 KiB of gathers in flight (~4 GB/s at ~2 us of
+// latency), eight waves on a CU approach that CU's ~24 GB/s.
+template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
@@ -93,6 +106,9 @@ template <class T, int NC, int SL = 0> struct RowEval {
     T* pbuf;  // p_j = F[ind_j,:] . x   for every nonzero of the row (CG line-search cache)
     T* qbuf;  // q_j = F[ind_j,:] . d
     int pq_cap;
+    T* red_part;      // NW > 1: [NW][s_load * SN] partial gradients, shared by the workgroup
+    double* red_l;    // NW > 1: [NW] partial log-likelihood sums
+    int wid;
     // launch constants
     const T* F;
     int k, s_load, s_stride, cap, tail;
@@ -124,7 +140,11 @@ template <class T, int NC, int SL = 0> struct RowEval {
         JG = WAVE / G;
         g = lane & (G - 1); jg = lane / G;
         tail = k - (s_load - 1) * SN;  // valid elements in the last slot of a factor row (1..SN)
-        unsigned char* p = smem;
+        wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
+        const size_t wave_bytes = lds_bytes_per_wave(geo, sizeof(T));
+        unsigned char* p = smem + (size_t)wid * wave_bytes;
+        red_l = (double*)(smem + (size_t)NW * wave_bytes);
+        red_part = (T*)(smem + (size_t)NW * wave_bytes + 16 * ((NW * sizeof(double) + 15) / 16));
         tile = (SA*)p; p += (size_t)cap * s_stride * 16;
         avec = (SA*)p; p += (size_t)s_load * 16;
         xb = (T*)p; p += (((size_t)cap * sizeof(T)) + 15) / 16 * 16;
@@ -182,7 +202,7 @@ template <class T, int NC, int SL = 0> struct RowEval {
     // registers -> global (copy 0 stores)
     __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
     {
-        if (jg == 0) {
+        if (jg == 0 && wid == 0) {
 #pragma unroll
             for (int i = 0; i < NC; i++)
                 if (act[i]) p[elem[i]] = x[i];
@@ -375,6 +395,30 @@ template <class T, int NC, int SL = 0> struct RowEval {
         for (int i = 0; i < NC; i++) acc[i] += part[i];
     }
 
+    // NW > 1: add up the NW waves' partial results (fixed order; every wave ends with the same bits)
+    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum) const
+    {
+        if constexpr (NW > 1) {
+            const int kp = s_load * SN;
+            if (jg == 0) {
+#pragma unroll
+                for (int i = 0; i < NC; i++)
+                    if (act[i]) red_part[wid * kp + elem[i]] = tot[i];
+            }
+            if (lane == 0) red_l[wid] = lsum;
+            __syncthreads();
+            lsum = 0.0;
+#pragma unroll
+            for (int i = 0; i < NC; i++) tot[i] = (T)0;
+            for (int w = 0; w < NW; w++) {
+                lsum += red_l[w];
+#pragma unroll
+                for (int i = 0; i < NC; i++) tot[i] += act[i] ? red_part[w * kp + elem[i]] : (T)0;
+            }
+            __syncthreads();  // the scratch is free again before anybody starts the next evaluation
+        }
+    }
+
     // At the point last published with set_point:
     //   WANT_F : returns lsum = sum_j x_j log(pred_j)   (log and the sum in double, as the reference's
     //            `lsum += X[ix] * log(dot)` is a double expression even in its float build)
@@ -386,7 +430,7 @@ template <class T, int NC, int SL = 0> struct RowEval {
         T part[NC];
 #pragma unroll
         for (int i = 0; i < NC; i++) part[i] = (T)0;
-        for (unsigned c0 = 0; c0 < nnz; c0 += (unsigned)cap) {
+        for (unsigned c0 = (unsigned)(wid * cap); c0 < nnz; c0 += (unsigned)(NW * cap)) {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
             if (!resident) load_chunk(c0, cn);
             for (int jb = 0; jb < cn; jb += WAVE) {
@@ -410,6 +454,20 @@ template <class T, int NC, int SL = 0> struct RowEval {
             }
         }
         PMF_T0(t4);
+        if constexpr (NW > 1) {
+            T tot[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) tot[i] = (T)0;
+            if constexpr (WANT_G) combine_groups(part, tot);
+            double lsum = 0.0;
+            if constexpr (WANT_F) lsum = wave_sum(lpart);
+            combine_waves(tot, lsum);
+            if constexpr (WANT_G) {
+#pragma unroll
+                for (int i = 0; i < NC; i++) acc[i] += tot[i];
+            }
+            return lsum;
+        }
         if constexpr (WANT_G) combine_groups(part, acc);
         PMF_T1(4, t4);
         if (store != nullptr) wave_lds_fence();
@@ -443,10 +501,21 @@ template <class T, int NC, int SL = 0> struct RowEval {
         T part[NC];
 #pragma unroll
         for (int i = 0; i < NC; i++) part[i] = (T)0;
-        for (unsigned c0 = 0; c0 < nnz; c0 += (unsigned)cap) {
+        for (unsigned c0 = (unsigned)(wid * cap); c0 < nnz; c0 += (unsigned)(NW * cap)) {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
             if (!resident) load_chunk(c0, cn);
             for (int jb = 0; jb < cn; jb += WAVE) accumulate<true>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
+        }
+        if constexpr (NW > 1) {
+            T tot[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) tot[i] = (T)0;
+            combine_groups(part, tot);
+            double unused = 0.0;
+            combine_waves(tot, unused);
+#pragma unroll
+            for (int i = 0; i < NC; i++) acc[i] += tot[i];
+            return;
         }
         combine_groups(part, acc);
     }

@@ -281,3 +281,21 @@ def test_transform_matches_fit_rows(prec):
     fo = H.half_objective(An, m.B, csr[0], csr[1], csr[2], m.Bsum, m.l2_reg_)
     fr = H.half_objective(Ao, m.B, csr[0], csr[1], csr[2], m.Bsum, m.l2_reg_)
     assert abs(fo - fr) <= T(prec, 1e-8, 1e-4) * abs(fr)
+
+
+# ------------------------------------------------------------------ long-row path: a workgroup of 8 waves per row
+@pytest.mark.parametrize("method,k", [("pg", 50), ("cg", 50), ("tncg", 50), ("cg", 100), ("pg", 7)])
+def test_long_row_workgroup_path(prec, method, k, monkeypatch):
+    """POISMF_HIP_LONGROW_NNZ lowers the threshold above which one row is handled by 8 cooperating wavefronts
+    (row_eval.hpp, NW > 1), so the path that the power-law tail of config C5 takes is exercised on a small matrix:
+    rows with 65 .. ~10^4 nonzeros go through it, shorter ones through the wave-per-row kernel."""
+    monkeypatch.setenv("POISMF_HIP_LONGROW_NNZ", "64")
+    csr, csc, A0, B0 = H.small_problem(3000, 2000, 120000, k, prec, seed=5, powerlaw=True, empty_rows=(3, 2999))
+    assert np.diff(csc[2].astype(np.int64)).max() > 2000
+    kw = dict(maxupd=60) if method == "tncg" else {}
+    A, B, args = gpu_run(csr, csc, A0, B0, method, 1, k, **kw)
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
+    if method == "pg" and prec and np.isfinite(Ar).all():
+        assert H.scaled_err(A, Ar) <= 1e-4 and H.scaled_err(B, Br) <= 1e-4
+    else:
+        compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
