@@ -299,3 +299,78 @@ def test_long_row_workgroup_path(prec, method, k, monkeypatch):
         assert H.scaled_err(A, Ar) <= 1e-4 and H.scaled_err(B, Br) <= 1e-4
     else:
         compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
+
+
+# ------------------------------------------------------------------ a14: SIGINT plumbing and return codes
+def test_sigint_returns_2_and_restores_handler():
+    """ref: src/poismf.c:444-455, :618-630 -- the handler is installed for the duration of the call, polled between
+    half-sweeps, the call returns 2 with A / B holding the state reached, and the previous handler is restored."""
+    import signal
+    import threading
+    import time as _time
+    csr, csc, A0, B0 = H.small_problem(20000, 5000, 400000, 50, False, seed=8, powerlaw=True)
+    seen = []
+    prev = signal.signal(signal.SIGINT, lambda *a: seen.append("python-handler"))
+    try:
+        def fire():
+            _time.sleep(0.15)
+            signal.raise_signal(signal.SIGINT) if False else os.kill(os.getpid(), signal.SIGINT)
+        th = threading.Thread(target=fire)
+        A, B = A0.copy(), B0.copy()
+        th.start()
+        t0 = _time.time()
+        # 400 outer iterations would take many seconds; the interrupt must cut it short
+        rc = api._run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], A, B, "cg", True, 1e4, 0., 1., 1e-7, 400, 5,
+                             False, False, True, 1)
+        dt = _time.time() - t0
+        th.join()
+        assert rc == 2 and dt < 10.0
+        assert np.isfinite(A).all() and not np.array_equal(A, A0)      # partial result was copied back
+        assert seen == []                                              # our C handler took it, not Python's
+        os.kill(os.getpid(), signal.SIGINT)                            # and Python's handler is back afterwards
+        _time.sleep(0.05)
+        assert seen == ["python-handler"]
+        # handle_interrupt = False: the signal is re-raised to the previous handler and the binding raises
+        seen.clear()
+        th = threading.Thread(target=fire)
+        th.start()
+        with pytest.raises(InterruptedError):
+            api._run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], A0.copy(), B0.copy(), "cg", True, 1e4, 0., 1.,
+                            1e-7, 400, 5, False, False, False, 1)
+        th.join()
+        _time.sleep(0.05)
+        assert seen == ["python-handler"]
+    finally:
+        signal.signal(signal.SIGINT, prev)
+
+
+def test_unsupported_k_is_a_loud_error():
+    csr, csc, A0, B0 = H.small_problem(50, 40, 300, 600, False, seed=1)   # k = 600 > 256 (fp64 limit)
+    with pytest.raises(MemoryError):
+        api._run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], A0.copy(), B0.copy(), "pg", True, 1e9, 0., 1., 1e-7, 1, 1)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 16, 17, 64, 65, 128, 129, 255, 256])
+def test_every_slot_geometry(prec, k):
+    """k sweeps the slot geometry: partial last slot, G = 16 / 32 / 64 lanes per copy, one and two slots per lane"""
+    if (not prec) and k > 256:
+        pytest.skip("fp64 limit")
+    csr, csc, A0, B0 = H.small_problem(300, 200, 6000, k, prec, seed=k)
+    # CG only in fp64: for k = 1..3 the fp32 problem is so flat that five noisy Armijo searches from a far start
+    # land anywhere (single rows differ by 100 % between ANY two summation orders, and a row that ends at exactly 0
+    # blows up its neighbours in the next half); the fp64 run exercises the identical code path.
+    for method in (("pg",) if prec else ("pg", "cg")):
+        kw = dict(maxupd=1) if method == "pg" else {}
+        A, B, args = gpu_run(csr, csc, A0, B0, method, 1, k, **kw)
+        Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
+        compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
+
+
+def test_zero_iterations_and_single_nonzero(prec):
+    csr, csc, A0, B0 = H.small_problem(10, 12, 1, 5, prec, seed=2)       # one nonzero in the whole matrix
+    A, B, args = gpu_run(csr, csc, A0, B0, "cg", 2, 5)
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, "cg", args)
+    compare(prec, "cg", csr, args, A, B, Ar, Br, converged=False)
+    assert np.count_nonzero(A.any(axis=1)) == 1 and np.count_nonzero(B.any(axis=1)) == 1
+    A, B, _ = gpu_run(csr, csc, A0, B0, "pg", 0, 5)                      # numiter = 0: factors come back untouched
+    assert np.array_equal(A, A0) and np.array_equal(B, B0)
