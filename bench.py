@@ -165,9 +165,13 @@ def main():
     ap.add_argument("--method", default="pg")
     ap.add_argument("--maxupd", type=int, default=None)
     ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--k", type=int, default=None, help="factor dimension (default 50: the BASELINE configs)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     a = ap.parse_args()
+    global K
+    if a.k:
+        K = a.k
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -106,6 +106,10 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     T* pbuf;  // p_j = F[ind_j,:] . x   for every nonzero of the row (CG line-search cache)
     T* qbuf;  // q_j = F[ind_j,:] . d
     int pq_cap;
+    // streamed rows: indices / values of the NEXT chunk travel in registers while the current chunk is processed
+    unsigned m_idx[2];
+    T m_x[2];
+    unsigned meta_c0; // first nonzero of the chunk whose indices / values sit in idxb / xb (0xffffffff: none)
     T* red_part;      // NW > 1: [NW][s_load * SN] partial gradients, shared by the workgroup
     double* red_l;    // NW > 1: [NW] partial log-likelihood sums
     int wid;
@@ -238,31 +242,85 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         }
     }
 
-    // Gather chunk [c0, c0+cn) of the current row: indices and values, then the factor rows.
-    __device__ __forceinline__ void load_chunk(unsigned c0, int cn)
+    // ---- chunk loading.  A chunk costs serialized memory round trips (~1.5-2 us each at load): its indices, then
+    // its factor rows.  Two measures keep that at ONE exposed round trip per chunk: (i) up to 16 loads per lane
+    // (16 KiB per wave) are put in flight before the first result is consumed; (ii) the indices / values of the
+    // next chunk are fetched into registers while the current chunk is gathered and processed (meta_prefetch),
+    // and dropped into LDS afterwards (meta_commit).
+    __device__ __forceinline__ void meta_prefetch(unsigned c0, int cn)
     {
-        PMF_T0(tg);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = lane + WAVE * u;
+            if (j < cn) { m_idx[u] = ind[c0 + j]; m_x[u] = val[c0 + j]; }
+        }
+    }
+    __device__ __forceinline__ void meta_commit(int cn)
+    {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = lane + WAVE * u;
+            if (j < cn) { idxb[j] = m_idx[u]; xb[j] = m_x[u]; }
+        }
+        wave_lds_fence();
+    }
+    __device__ __forceinline__ void meta_load(unsigned c0, int cn)
+    {
         for (int j = lane; j < cn; j += WAVE) {
             idxb[j] = ind[c0 + j];
             xb[j] = val[c0 + j];
         }
         wave_lds_fence();
+    }
+    // factor rows of the chunk whose indices are in idxb -> tile
+    __device__ __forceinline__ void gather_tile(int cn)
+    {
         const int Q = cn * s_load;  // 16-byte slots to fetch
         int j = gj0, t = gt0;
         int q0 = 0;
-        for (; q0 + 8 * WAVE <= Q; q0 += 8 * WAVE) gather_batch<8>(q0, Q, j, t);  // 8 KiB in flight per wave
+        for (; q0 + 16 * WAVE <= Q; q0 += 16 * WAVE) gather_batch<16>(q0, Q, j, t);
         const int rem = Q - q0;
-        if (rem > 4 * WAVE) gather_batch<8>(q0, Q, j, t);
+        if (rem > 8 * WAVE) gather_batch<16>(q0, Q, j, t);
+        else if (rem > 4 * WAVE) gather_batch<8>(q0, Q, j, t);
         else if (rem > 2 * WAVE) gather_batch<4>(q0, Q, j, t);
         else if (rem > WAVE) gather_batch<2>(q0, Q, j, t);
         else if (rem > 0) gather_batch<1>(q0, Q, j, t);
         wave_lds_fence();
+    }
+    __device__ __forceinline__ void load_chunk(unsigned c0, int cn)
+    {
+        PMF_T0(tg);
+        meta_load(c0, cn);
+        gather_tile(cn);
         PMF_T1(0, tg);
+    }
+    // One chunk of a STREAMED row: uses prefetched indices when they are there, and prefetches those of the chunk
+    // this wave will need next (the following one, or -- at the end of a pass -- the first one again, for the next
+    // pass).  Call stream_chunk_done() after the chunk has been processed.
+    __device__ __forceinline__ void stream_chunk_begin(unsigned c0, int cn, unsigned& nc0, int& ncn)
+    {
+        PMF_T0(tg);
+        if (meta_c0 != c0) { meta_load(c0, cn); meta_c0 = c0; }
+        nc0 = c0 + (unsigned)(NW * cap);
+        if (nc0 >= nnz) nc0 = (unsigned)(wid * cap);   // wrap: the first chunk again, for the next pass over the row
+        ncn = (int)((nnz - nc0 < (unsigned)cap) ? nnz - nc0 : (unsigned)cap);
+        if (nc0 != c0 && cap <= 2 * WAVE) meta_prefetch(nc0, ncn);
+        else ncn = 0;                                  // single-chunk row, or chunk too large for two registers per lane
+        gather_tile(cn);
+        PMF_T1(0, tg);
+    }
+    __device__ __forceinline__ void stream_chunk_done(unsigned nc0, int ncn)
+    {
+        if (ncn > 0) {
+            meta_commit(ncn);
+            meta_c0 = nc0;
+        }
     }
 
     __device__ __forceinline__ void begin_row(const unsigned* ind_, const T* val_, unsigned nnz_)
     {
         ind = ind_; val = val_; nnz = nnz_;
+        meta_c0 = 0xffffffffu;
         if (resident && nnz > 0) load_chunk(0, (int)nnz);
     }
 
@@ -432,7 +490,9 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         for (int i = 0; i < NC; i++) part[i] = (T)0;
         for (unsigned c0 = (unsigned)(wid * cap); c0 < nnz; c0 += (unsigned)(NW * cap)) {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
-            if (!resident) load_chunk(c0, cn);
+            unsigned nc0 = 0;
+            int ncn = 0;
+            if (!resident) stream_chunk_begin(c0, cn, nc0, ncn);
             for (int jb = 0; jb < cn; jb += WAVE) {
                 PMF_T0(t1);
                 const T pred = pred_lane(jb, cn);
@@ -452,6 +512,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
                     PMF_T1(3, t3);
                 }
             }
+            if (!resident) stream_chunk_done(nc0, ncn);
         }
         PMF_T0(t4);
         if constexpr (NW > 1) {
@@ -503,8 +564,11 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         for (int i = 0; i < NC; i++) part[i] = (T)0;
         for (unsigned c0 = (unsigned)(wid * cap); c0 < nnz; c0 += (unsigned)(NW * cap)) {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
-            if (!resident) load_chunk(c0, cn);
+            unsigned nc0 = 0;
+            int ncn = 0;
+            if (!resident) stream_chunk_begin(c0, cn, nc0, ncn);
             for (int jb = 0; jb < cn; jb += WAVE) accumulate<true>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
+            if (!resident) stream_chunk_done(nc0, ncn);
         }
         if constexpr (NW > 1) {
             T tot[NC];
