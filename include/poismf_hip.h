@@ -81,6 +81,21 @@ POISMF_HIP_API int factors_multiple(
     int nthreads);
 
 /* ---------------------------------------------------------------------------------------------
+ * 1c. COO -> CSR + CSC on the device.
+ *
+ * Replaces: the SciPy conversions of PoisMF._process_data, ref: poismf/__init__.py:404-414 (coo.tocsr() and
+ * coo.tocsc(): duplicate (i,j) entries summed, indices sorted within each row / column, then cast to real_t /
+ * size_t).  There is no C function for this in the reference; the entry point takes what _process_data holds
+ * (host triplets) and fills what run_poismf takes.  Output arrays are caller-allocated with capacity n
+ * (values, indices) and dim + 1 (indptr); *nnz_out receives the number of distinct (i,j).  Requires n < 2^32.
+ * Returns 0, or 1 when out of memory / no device.
+ * ------------------------------------------------------------------------------------------- */
+POISMF_HIP_API int poismf_hip_coo_to_csr_csc(
+    const sparse_ix *row, const sparse_ix *col, const real_t *val, size_t n, size_t dimA, size_t dimB,
+    real_t *csr_val, sparse_ix *csr_indices, sparse_ix *csr_indptr,
+    real_t *csc_val, sparse_ix *csc_indices, sparse_ix *csc_indptr, size_t *nnz_out);
+
+/* ---------------------------------------------------------------------------------------------
  * 2. Device-resident session: the same path with X, A and B kept in HBM between calls, one
  *    half-sweep per call.  This is what bench.py times (inputs already resident) and what the
  *    one-process-per-GPU driver uses: each rank owns a contiguous range of A rows and of B rows,

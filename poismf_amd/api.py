@@ -38,7 +38,7 @@ def _params_type(c_real):
 
 # every symbol include/poismf_hip.h declares
 EXPORTED_SYMBOLS = (
-    "run_poismf", "factors_multiple", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
+    "run_poismf", "factors_multiple", "poismf_hip_coo_to_csr_csc", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
     "poismf_hip_session_B", "poismf_hip_session_set_factors", "poismf_hip_session_get_factors",
     "poismf_hip_half_sweep", "poismf_hip_session_profile", "poismf_hip_session_kernel_time",
     "poismf_hip_session_nnz",
@@ -61,6 +61,8 @@ def load_library(use_float):
     lib.run_poismf.restype = i
     lib.factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
     lib.factors_multiple.restype = i
+    lib.poismf_hip_coo_to_csr_csc.argtypes = [vp, vp, vp, sz, sz, sz] + [vp] * 6 + [C.POINTER(sz)]
+    lib.poismf_hip_coo_to_csr_csc.restype = i
     lib.poismf_hip_session_create.argtypes = [C.POINTER(vp), i, vp] + [vp] * 6 + [sz] * 3 + [sz] * 4
     lib.poismf_hip_session_create.restype = i
     lib.poismf_hip_session_destroy.argtypes = [vp]
@@ -123,6 +125,28 @@ def _run_poismf(Xr, Xr_indices, Xr_indptr, Xc, Xc_indices, Xc_indptr, A, B, meth
     elif ret == 2 and not handle_interrupt:
         raise InterruptedError("Procedure was interrupted")                         # ref: pxi:106-107
     return ret
+
+
+def coo_to_csr_csc(coo, use_float):
+    """GPU replacement of harness.process_data (ref: poismf/__init__.py:404-414): SciPy COO -> (csr, csc) tuples of
+    (data real_t, indices size_t, indptr size_t) with duplicates summed and indices sorted."""
+    lib = load_library(use_float)
+    dt = np.float32 if use_float else np.float64
+    n = coo.nnz
+    if n == 0:
+        raise ValueError("'X' contains no non-zero entries.")
+    row = np.ascontiguousarray(coo.row, dtype=np.uint64)
+    col = np.ascontiguousarray(coo.col, dtype=np.uint64)
+    val = np.ascontiguousarray(coo.data, dtype=dt)
+    dimA, dimB = coo.shape
+    cv, ci, cp = np.empty(n, dt), np.empty(n, np.uint64), np.empty(dimA + 1, np.uint64)
+    kv, ki, kp = np.empty(n, dt), np.empty(n, np.uint64), np.empty(dimB + 1, np.uint64)
+    nnz = C.c_size_t(0)
+    if lib.poismf_hip_coo_to_csr_csc(_ptr(row), _ptr(col), _ptr(val), n, dimA, dimB, _ptr(cv), _ptr(ci), _ptr(cp), _ptr(kv),
+                                     _ptr(ki), _ptr(kp), C.byref(nnz)):
+        raise MemoryError("Could not allocate enough memory.")
+    m = nnz.value
+    return (cv[:m].copy(), ci[:m].copy(), cp), (kv[:m].copy(), ki[:m].copy(), kp)
 
 
 def _predict_factors_multiple(B, Bsum, Amean, Xr_indptr, Xr_indices, Xr, l2_reg=1e9, w_mult=1., step_size=1e-7,

@@ -374,3 +374,26 @@ def test_zero_iterations_and_single_nonzero(prec):
     assert np.count_nonzero(A.any(axis=1)) == 1 and np.count_nonzero(B.any(axis=1)) == 1
     A, B, _ = gpu_run(csr, csc, A0, B0, "pg", 0, 5)                      # numiter = 0: factors come back untouched
     assert np.array_equal(A, A0) and np.array_equal(B, B0)
+
+
+# ------------------------------------------------------------------ N3: COO -> CSR + CSC on the device
+@pytest.mark.parametrize("shape,n,seed", [((100, 1000), 10000, 1), ((3000, 2000), 200000, 2), ((7, 5), 200, 3), ((50000, 40000), 2000000, 4)])
+def test_coo_conversion_is_bit_identical_to_scipy(prec, shape, n, seed):
+    """integer / index work: exact.  Values are small integer counts, so the duplicate sums are exact in any order."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    row, col = rng.integers(0, shape[0], n), rng.integers(0, shape[1], n)
+    val = 1.0 + np.floor(rng.gamma(1.0, 1.0, n))
+    coo = sp.coo_matrix((val, (row, col)), shape=shape)
+    csr_g, csc_g = api.coo_to_csr_csc(coo, prec)
+    csr_h, csc_h = harness.process_data(coo, prec)
+    for g_, h_ in ((csr_g, csr_h), (csc_g, csc_h)):
+        for a, b in zip(g_, h_):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def test_readme_data_through_gpu_conversion(prec):
+    from poismf_amd import synth
+    coo = synth.readme_coo()
+    csr, csc = api.coo_to_csr_csc(coo, prec)
+    assert len(csr[0]) == 9490 and csr[0].sum() == coo.data.sum() == csc[0].sum()
