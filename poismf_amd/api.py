@@ -195,7 +195,9 @@ class PoisMF:
         self.is_fitted = False
 
     def fit(self, X):
-        csr, csc = harness.process_data(X, self.use_float)
+        # COO -> CSR + CSC on the device (bit-identical to the SciPy conversion of the reference's _process_data)
+        import scipy.sparse as sp
+        csr, csc = coo_to_csr_csc(sp.coo_matrix(X), self.use_float)
         self.nusers, self.nitems = X.shape
         self.A, self.B = harness.initialize_matrices(self.nusers, self.nitems, self.k, self.use_float,
                                                      self.random_state)

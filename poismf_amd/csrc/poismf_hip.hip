@@ -141,17 +141,33 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
 // ---- column sums of a dense [n x k] factor: sum_by_cols, ref: src/poismf.c:77-83 ---------------------
 // stage 1: wave w accumulates rows w, w + nw, ...; stage 2: one wave adds the nw partials in order,
 // then applies `+ l1` (ref: :513-514) and the PG pre-scalings (ref: :523-526, :573-577, quirk Q1).
+// stage 1: blocks of 8 waves; wave w of block b accumulates rows (b*8 + w), + 8*grid, ...; the 8 wave totals are added
+// through LDS in wave order, so the 256-way partial written by the block is bit-reproducible.
+constexpr int COLSUM_BLOCK_WAVES = 8;
 template <class T, int NC>
-__global__ __launch_bounds__(WAVE) void colsum_partial_kernel(const T* M, size_t n, int k, T* partial)
+__global__ __launch_bounds__(WAVE* COLSUM_BLOCK_WAVES) void colsum_partial_kernel(const T* M, size_t n, int k, T* partial)
 {
+    __shared__ T part[COLSUM_BLOCK_WAVES][NC * WAVE];
     const int lane = lane_id();
+    const int w = (int)(threadIdx.x / WAVE);
     T acc[NC];
     PMF_EW acc[i] = (T)0;
-    for (size_t r = blockIdx.x; r < n; r += gridDim.x) {
+    for (size_t r = (size_t)blockIdx.x * COLSUM_BLOCK_WAVES + w; r < n; r += (size_t)gridDim.x * COLSUM_BLOCK_WAVES) {
         const T* row = M + r * (size_t)k;
         PMF_EW if (lane + WAVE * i < k) acc[i] += row[lane + WAVE * i];
     }
-    PMF_EW if (lane + WAVE * i < k) partial[(size_t)blockIdx.x * k + lane + WAVE * i] = acc[i];
+    PMF_EW part[w][lane + WAVE * i] = acc[i];
+    __syncthreads();
+    if (w == 0) {
+        PMF_EW {
+            const int c = lane + WAVE * i;
+            if (c < k) {
+                T s = part[0][c];
+                for (int q = 1; q < COLSUM_BLOCK_WAVES; q++) s += part[q][c];
+                partial[(size_t)blockIdx.x * k + c] = s;
+            }
+        }
+    }
 }
 // stage 2: 16 waves; wave w adds partials w, w + 16, ... in order, then wave 0 adds the 16 wave totals in order
 // (fixed summation order => bit-reproducible), applies `+ l1` and the PG pre-scalings.
@@ -236,7 +252,7 @@ struct poismf_hip_session {
     real_t* d_partial = nullptr;
     unsigned* d_counter = nullptr;
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
-    int colsum_waves = 1024;
+    int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
     bool profiling = false;
     std::vector<ProfRec> prof;
 };
@@ -387,8 +403,9 @@ int slots_per_lane(size_t k)
 
 template <int NC> int launch_colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
 {
-    const int nw = (int)std::min<size_t>((size_t)s->colsum_waves, std::max<size_t>(n, 1));
-    hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(nw), dim3(WAVE), 0, s->stream, M, n, (int)s->k, s->d_partial);
+    const int nw = (int)std::min<size_t>((size_t)s->colsum_waves, std::max<size_t>((n + COLSUM_BLOCK_WAVES - 1) / COLSUM_BLOCK_WAVES, 1));
+    hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(nw), dim3(WAVE * COLSUM_BLOCK_WAVES), 0, s->stream, M, n, (int)s->k,
+                       s->d_partial);
     hipLaunchKernelGGL((colsum_final_kernel<real_t, NC>), dim3(1), dim3(WAVE * COLSUM_FINAL_WAVES), 0, s->stream, s->d_partial, nw, (int)s->k, l1,
                        scale, nscale, s->d_bsum);
     HIP_TRY(hipGetLastError());

@@ -397,3 +397,17 @@ def test_readme_data_through_gpu_conversion(prec):
     coo = synth.readme_coo()
     csr, csc = api.coo_to_csr_csc(coo, prec)
     assert len(csr[0]) == 9490 and csr[0].sum() == coo.data.sum() == csc[0].sum()
+
+
+def test_fit_end_to_end_matches_reference_recipe(prec):
+    """PoisMF.fit (device COO conversion + run_poismf) == host conversion + oracle, README data, method=cg"""
+    from poismf_amd import synth
+    coo = synth.readme_coo()
+    m = api.PoisMF(k=5, method="cg", use_float=prec, random_state=1).fit(coo)
+    csr, csc, A0, B0 = H.c1_problem(prec)
+    l2, maxupd, niter = harness.auto_defaults("cg", 5)
+    args = dict(l2_reg=l2, l1_reg=0.0, w_mult=1.0, step_size=1e-7, limit_step=True, niter=niter, maxupd=maxupd,
+                early_stop=True, reuse_prev=False)
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, "cg", args)
+    compare(prec, "cg", csr, args, m.A, m.B, Ar, Br, converged=True)
+    assert np.allclose(m.Bsum, m.B.sum(axis=0)) and np.allclose(m.Amean, m.A.mean(axis=0))
