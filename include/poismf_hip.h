@@ -96,6 +96,24 @@ POISMF_HIP_API int poismf_hip_coo_to_csr_csc(
     real_t *csc_val, sparse_ix *csc_indices, sparse_ix *csc_indptr, size_t *nnz_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * 1d. Serving-side helpers.
+ *
+ * Replaces: predict_multiple, ref: src/poismf.h:250-257 (prototype), src/pred.c:42-64;
+ *           topN,             ref: src/poismf.h:240-247 (prototype), src/topN.c:112-284.
+ * Same names, argument order and return codes (topN: 0 ok, 1 out of memory / no device, 2 invalid combination of
+ * include / exclude / n_top as at ref src/topN.c:126-130).  Among equal scores topN returns ascending indices (the
+ * reference leaves that order to qsort).  Host pointers in and out; the factors are copied to the device per call.
+ * ------------------------------------------------------------------------------------------- */
+POISMF_HIP_API void predict_multiple(
+    real_t *out, real_t *A, real_t *B, sparse_ix *ixA, sparse_ix *ixB, size_t n, int k, int nthreads);
+POISMF_HIP_API int topN(
+    real_t *a_vec, real_t *B, int k,
+    sparse_ix *include_ix, size_t n_include,
+    sparse_ix *exclude_ix, size_t n_exclude,
+    sparse_ix *outp_ix, real_t *outp_score,
+    size_t n_top, size_t n, int nthreads);
+
+/* ---------------------------------------------------------------------------------------------
  * 2. Device-resident session: the same path with X, A and B kept in HBM between calls, one
  *    half-sweep per call.  This is what bench.py times (inputs already resident) and what the
  *    one-process-per-GPU driver uses: each rank owns a contiguous range of A rows and of B rows,

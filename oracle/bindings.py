@@ -83,6 +83,10 @@ class Oracle(_Lib):
         L.oracle_run_poismf.restype = i
         L.oracle_factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
         L.oracle_factors_multiple.restype = i
+        L.oracle_predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
+        L.oracle_predict_multiple.restype = None
+        L.oracle_topn.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz]
+        L.oracle_topn.restype = i
 
     # ---- G1 primitives -------------------------------------------------------------------
     def calc_grad_pgd(self, a, F, xval, xind):
@@ -161,6 +165,18 @@ class Oracle(_Lib):
 
     _fm_symbol = "oracle_factors_multiple"
 
+    def predict_multiple(self, A, B, ixA, ixB, nthreads=1):
+        out = np.empty(len(ixA), self.np_t)
+        self.lib.oracle_predict_multiple(_p(out), _p(A), _p(B), _p(ixA), _p(ixB), len(ixA), A.shape[1], nthreads)
+        return out
+
+    def topn(self, a_vec, B, include_ix, exclude_ix, n_top):
+        ix = np.empty(n_top, np.uint64)
+        sc = np.empty(n_top, self.np_t)
+        rc = self.lib.oracle_topn(_p(a_vec), _p(B), B.shape[1], _p(include_ix) if len(include_ix) else None, len(include_ix),
+                                  _p(exclude_ix) if len(exclude_ix) else None, len(exclude_ix), _p(ix), _p(sc), n_top, B.shape[0])
+        return rc, ix, sc
+
     def factors_multiple(self, B, Bsum, Amean, Xr, Xr_indptr, Xr_indices, l2_reg, w_mult, step_size, niter, maxupd,
                          method, limit_step, reuse_mean, nthreads=1):
         """ref: src/pred.c:66-199; argument meaning of poismf_c_wrapper.pxi:147-160.  Returns A [n_new x k]."""
@@ -225,6 +241,10 @@ class Reference(_Lib):
         L.run_poismf.restype = i
         L.factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
         L.factors_multiple.restype = i
+        L.predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
+        L.predict_multiple.restype = None
+        L.topN.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz, i]
+        L.topN.restype = i
 
     def _fd(self, F, bsum, xval, xind, l2, w):
         return self.FData(F.ctypes.data, bsum.ctypes.data, xval.ctypes.data, xind.ctypes.data, len(xval),
@@ -343,3 +363,17 @@ class Reference(_Lib):
                 step_size, niter, maxupd, METHOD[method], bool(limit_step), bool(reuse_mean), nthreads)
         assert rc == 0
         return A
+
+    def predict_multiple(self, A, B, ixA, ixB, nthreads=1):
+        out = np.empty(len(ixA), self.np_t)
+        self.lib.predict_multiple(_p(out), _p(A), _p(B), _p(ixA), _p(ixB), len(ixA), A.shape[1], nthreads)
+        return out
+
+    def topn(self, a_vec, B, include_ix, exclude_ix, n_top):
+        ix = np.empty(n_top, np.uint64)
+        sc = np.empty(n_top, self.np_t)
+        inc = include_ix.copy()
+        exc = exclude_ix.copy()  # the reference sorts / permutes its index arguments in place
+        rc = self.lib.topN(_p(a_vec), _p(B), B.shape[1], _p(inc) if len(inc) else None, len(inc), _p(exc) if len(exc) else None,
+                           len(exc), _p(ix), _p(sc), n_top, B.shape[0], 1)
+        return rc, ix, sc

@@ -1265,3 +1265,58 @@ ORC_API int oracle_factors_multiple(real_t *A, real_t *B, real_t *Bsum, real_t *
     free(bsum_w); free(bsum_w_scaled); free(bsum_scaled);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Serving-side helpers                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+/* ref: src/pred.c:42-64 (predict_multiple) */
+ORC_API void oracle_predict_multiple(real_t *out, const real_t *A, const real_t *B, const sparse_ix *ixA,
+                                     const sparse_ix *ixB, size_t n, int k, int nthreads)
+{
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (size_t i = 0; i < n; i++)
+        out[i] = vdot(k, A + (size_t)ixA[i] * (size_t)k, B + (size_t)ixB[i] * (size_t)k);
+}
+
+/* ref: src/topN.c:112-284 (topN).  The reference's three code paths (include list, large exclude list, gemv +
+   partial argsort) all compute the same thing: the n_top best-scoring candidates in descending score order.  The
+   order among EQUAL scores is whatever its qsort / quickselect leaves, i.e. unspecified; this restatement breaks
+   ties by ascending index.  Return codes as at ref :126-130. */
+typedef struct { real_t s; sparse_ix j; } scored_t;
+static int cmp_scored(const void *a, const void *b)
+{
+    const scored_t *x = (const scored_t *)a, *y = (const scored_t *)b;
+    if (x->s != y->s) return (x->s < y->s) ? 1 : -1;
+    return (x->j > y->j) - (x->j < y->j);
+}
+ORC_API int oracle_topn(const real_t *a_vec, const real_t *B, int k, const sparse_ix *include_ix, size_t n_include,
+                        const sparse_ix *exclude_ix, size_t n_exclude, sparse_ix *outp_ix, real_t *outp_score,
+                        size_t n_top, size_t n)
+{
+    if (n_include == 0) include_ix = NULL;
+    if (n_exclude == 0) exclude_ix = NULL;
+    if (include_ix != NULL && exclude_ix != NULL) return 2;
+    if (n_top == 0) return 2;
+    if (n_exclude > n - n_top) return 2;
+    if (n_include > n) return 2;
+    size_t n_cand = include_ix ? n_include : n;
+    if (n_top > n_cand) return 2;
+    scored_t *c = (scored_t *)malloc(sizeof(scored_t) * n_cand);
+    char *skip = (char *)calloc(n, 1);
+    if (exclude_ix) for (size_t i = 0; i < n_exclude; i++) skip[exclude_ix[i]] = 1;
+    size_t m = 0;
+    for (size_t i = 0; i < n_cand; i++) {
+        sparse_ix j = include_ix ? include_ix[i] : (sparse_ix)i;
+        if (!include_ix && skip[j]) continue;
+        c[m].j = j;
+        c[m].s = vdot(k, a_vec, B + (size_t)j * (size_t)k);
+        m++;
+    }
+    qsort(c, m, sizeof(scored_t), cmp_scored);
+    for (size_t i = 0; i < n_top; i++) {
+        outp_ix[i] = c[i].j;
+        if (outp_score) outp_score[i] = c[i].s;
+    }
+    free(c); free(skip);
+    return 0;
+}

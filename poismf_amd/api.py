@@ -38,7 +38,7 @@ def _params_type(c_real):
 
 # every symbol include/poismf_hip.h declares
 EXPORTED_SYMBOLS = (
-    "run_poismf", "factors_multiple", "poismf_hip_coo_to_csr_csc", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
+    "run_poismf", "factors_multiple", "poismf_hip_coo_to_csr_csc", "predict_multiple", "topN", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
     "poismf_hip_session_B", "poismf_hip_session_set_factors", "poismf_hip_session_get_factors",
     "poismf_hip_half_sweep", "poismf_hip_session_profile", "poismf_hip_session_kernel_time",
     "poismf_hip_session_nnz",
@@ -61,6 +61,10 @@ def load_library(use_float):
     lib.run_poismf.restype = i
     lib.factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
     lib.factors_multiple.restype = i
+    lib.predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
+    lib.predict_multiple.restype = None
+    lib.topN.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz, i]
+    lib.topN.restype = i
     lib.poismf_hip_coo_to_csr_csc.argtypes = [vp, vp, vp, sz, sz, sz] + [vp] * 6 + [C.POINTER(sz)]
     lib.poismf_hip_coo_to_csr_csc.restype = i
     lib.poismf_hip_session_create.argtypes = [C.POINTER(vp), i, vp] + [vp] * 6 + [sz] * 3 + [sz] * 4
@@ -147,6 +151,33 @@ def coo_to_csr_csc(coo, use_float):
         raise MemoryError("Could not allocate enough memory.")
     m = nnz.value
     return (cv[:m].copy(), ci[:m].copy(), cp), (kv[:m].copy(), ki[:m].copy(), kp)
+
+
+def _predict_multiple(out, A, B, ix_u, ix_i, nthreads=1):
+    """Drop-in for c_funs._predict_multiple (ref: poismf/poismf_c_wrapper.pxi:109-112): out[i] = A[ix_u[i]] . B[ix_i[i]]."""
+    use_float = A.dtype == np.float32
+    _check_arrays(use_float, (out, A, B), (ix_u, ix_i))
+    load_library(use_float).predict_multiple(_ptr(out), _ptr(A), _ptr(B), _ptr(ix_u), _ptr(ix_i), ix_u.shape[0], A.shape[1],
+                                             int(nthreads))
+
+
+def _call_topN(a_vec, B, include_ix, exclude_ix, top_n=10, output_score=0, nthreads=1):
+    """Drop-in for c_funs._call_topN (ref: poismf/poismf_c_wrapper.pxi:207-246): returns (indices, scores)."""
+    use_float = B.dtype == np.float32
+    _check_arrays(use_float, (a_vec, B), (include_ix, exclude_ix))
+    dt = B.dtype
+    n_inc = include_ix.shape[0]
+    n_exc = 0 if n_inc else exclude_ix.shape[0]
+    outp_ix = np.empty(top_n, dtype=np.uint64)
+    outp_score = np.empty(top_n if output_score else 0, dtype=dt)
+    rc = load_library(use_float).topN(_ptr(a_vec), _ptr(B), B.shape[1], _ptr(include_ix) if n_inc else None, n_inc,
+                                      _ptr(exclude_ix) if n_exc else None, n_exc, _ptr(outp_ix),
+                                      _ptr(outp_score) if output_score else None, int(top_n), B.shape[0], int(nthreads))
+    if rc == 1:
+        raise MemoryError("Could not allocate enough memory.")
+    if rc == 2:
+        raise ValueError("invalid combination of include / exclude / top_n")
+    return outp_ix, outp_score
 
 
 def _predict_factors_multiple(B, Bsum, Amean, Xr_indptr, Xr_indices, Xr, l2_reg=1e9, w_mult=1., step_size=1e-7,

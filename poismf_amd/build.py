@@ -15,6 +15,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "poismf_hip.h")
 UNITS = {
     "poismf_hip": ["poismf_hip.hip", "solvers.hpp", "row_eval.hpp", "wave_ops.hpp"],
     "coo_convert": ["coo_convert.hip"],
+    "serve": ["serve.hip"],
 }
 
 

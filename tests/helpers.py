@@ -77,3 +77,22 @@ def frac_rows_close(X, ref, tol):
     X, ref = np.asarray(X, np.float64), np.asarray(ref, np.float64)
     scale = max(float(np.max(np.abs(ref))), 1e-300)
     return float(np.mean(np.max(np.abs(X - ref), axis=1) <= tol * scale))
+
+
+def check_topn(a_vec, B, idx, scores, include_ix, exclude_ix, n_top, rtol):
+    """A top-N answer is right if (i) it lists n_top distinct admissible items, (ii) in non-increasing score order,
+    (iii) the reported scores are the items' scores, and (iv) no admissible item left out beats the last one listed
+    by more than rounding -- which is all the reference promises (equal scores come back in qsort's order)."""
+    true = np.asarray(B, np.float64) @ np.asarray(a_vec, np.float64)
+    idx = np.asarray(idx, np.int64)
+    assert len(idx) == n_top and len(set(idx.tolist())) == n_top
+    cand = np.asarray(include_ix, np.int64) if len(include_ix) else np.setdiff1d(np.arange(B.shape[0]), np.asarray(exclude_ix, np.int64))
+    assert np.isin(idx, cand).all()
+    tol = rtol * max(float(np.max(np.abs(true))), 1e-300)
+    s = true[idx]
+    assert np.all(s[:-1] >= s[1:] - tol)
+    if scores is not None and len(scores):
+        assert np.max(np.abs(np.asarray(scores, np.float64) - s)) <= tol
+    left_out = np.setdiff1d(cand, idx)
+    if len(left_out):
+        assert true[left_out].max() <= s[-1] + tol

@@ -411,3 +411,40 @@ def test_fit_end_to_end_matches_reference_recipe(prec):
     Ar, Br = oracle_run(prec, csr, csc, A0, B0, "cg", args)
     compare(prec, "cg", csr, args, m.A, m.B, Ar, Br, converged=True)
     assert np.allclose(m.Bsum, m.B.sum(axis=0)) and np.allclose(m.Amean, m.A.mean(axis=0))
+
+
+# ------------------------------------------------------------------ N4: predict_multiple and topN
+def test_predict_multiple_gpu(prec):
+    rng = np.random.default_rng(3)
+    dt = np.float32 if prec else np.float64
+    A, B = rng.random((3000, 50)).astype(dt), rng.random((20000, 50)).astype(dt)
+    iu = rng.integers(0, 3000, 100000).astype(np.uint64)
+    ii = rng.integers(0, 20000, 100000).astype(np.uint64)
+    out = np.empty(len(iu), dt)
+    api._predict_multiple(out, A, B, iu, ii, 1)
+    ref = bindings.Oracle(prec).predict_multiple(A, B, iu, ii)
+    assert H.scaled_err(out, ref) <= T(prec, 1e-14, 1e-6)
+
+
+@pytest.mark.parametrize("case", ["all", "include", "exclude_many", "exclude_few", "most"])
+def test_topn_gpu(prec, case):
+    rng = np.random.default_rng(4)
+    dt = np.float32 if prec else np.float64
+    B = rng.random((50000, 50)).astype(dt)
+    a = rng.random(50).astype(dt)
+    none = np.empty(0, np.uint64)
+    inc, exc, nt = {"all": (none, none, 10),
+                    "include": (np.sort(rng.choice(50000, 700, replace=False)).astype(np.uint64), none, 15),
+                    "exclude_many": (none, np.sort(rng.choice(50000, 9000, replace=False)).astype(np.uint64), 25),
+                    "exclude_few": (none, rng.choice(50000, 40, replace=False).astype(np.uint64), 7),
+                    "most": (none, none, 40000)}[case]
+    ix, sc = api._call_topN(a, B, inc, exc, nt, 1, 1)
+    H.check_topn(a, B, ix, sc, inc, exc, nt, T(prec, 1e-13, 1e-5))
+    rc, ixo, sco = bindings.Oracle(prec).topn(a, B, inc, exc, nt)
+    assert rc == 0
+    if case != "most" and not prec:   # fp32 near-ties may swap with the summation order; check_topn above covers that
+        assert np.array_equal(ix, ixo)
+    ix2, sc2 = api._call_topN(a, B, inc, exc, nt, 0, 1)
+    assert np.array_equal(ix2, ix) and len(sc2) == 0
+    with pytest.raises(ValueError):
+        api._call_topN(a, B, none, np.arange(49999, dtype=np.uint64), 5, 0, 1)   # n_exclude > n - n_top

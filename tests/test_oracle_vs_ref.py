@@ -266,3 +266,45 @@ def test_factors_multiple(libs, method, w, reuse):
         fo = H.half_objective(a, B0, csr[0], csr[1], csr[2], Bsum, l2 if method == "cg" else 0.0, w)
         fr = H.half_objective(b, B0, csr[0], csr[1], csr[2], Bsum, l2 if method == "cg" else 0.0, w)
         assert abs(fo - fr) <= tol(is_float, 1e-6, 2e-2) * abs(fr)
+
+
+# ---------------------------------------------------------------- N4: predict_multiple, topN
+def _serve_inputs(is_float, seed=0):
+    rng = np.random.default_rng(seed)
+    dt = np.float32 if is_float else np.float64
+    A = rng.random((300, 20)).astype(dt)
+    B = rng.random((5000, 20)).astype(dt)
+    return rng, A, B
+
+
+def test_predict_multiple(libs):
+    orc, ref, is_float = libs
+    rng, A, B = _serve_inputs(is_float)
+    ia = rng.integers(0, 300, 2000).astype(np.uint64)
+    ib = rng.integers(0, 5000, 2000).astype(np.uint64)
+    o, r = orc.predict_multiple(A, B, ia, ib), ref.predict_multiple(A, B, ia, ib)
+    if _EXACT["on"]:
+        assert np.array_equal(o, r)
+    else:
+        assert H.scaled_err(o, r) <= tol(is_float, 1e-14, 1e-6)
+
+
+@pytest.mark.parametrize("case", ["all", "include", "exclude_many", "exclude_few", "most"])
+def test_topn(libs, case):
+    orc, ref, is_float = libs
+    rng, A, B = _serve_inputs(is_float, 1)
+    none = np.empty(0, np.uint64)
+    inc, exc, nt = {"all": (none, none, 10),
+                    "include": (np.sort(rng.choice(5000, 300, replace=False)).astype(np.uint64), none, 10),
+                    "exclude_many": (none, np.sort(rng.choice(5000, 1000, replace=False)).astype(np.uint64), 25),
+                    "exclude_few": (none, rng.choice(5000, 40, replace=False).astype(np.uint64), 7),
+                    "most": (none, none, 4000)}[case]
+    a = A[3].copy()
+    for lib in (orc, ref):
+        rc, ix, sc = lib.topn(a, B, inc, exc, nt)
+        assert rc == 0
+        H.check_topn(a, B, ix, sc, inc, exc, nt, tol(is_float, 1e-13, 1e-5) if not _EXACT["on"] else (1e-5 if is_float else 1e-13))
+    if case != "most":  # no near-ties among the first few: identical answers
+        assert np.array_equal(orc.topn(a, B, inc, exc, nt)[1], ref.topn(a, B, inc, exc, nt)[1])
+    assert orc.topn(a, B, inc[:3] if len(inc) else np.arange(3, dtype=np.uint64), np.arange(3, dtype=np.uint64), 2)[0] == 2
+    assert ref.topn(a, B, np.arange(3, dtype=np.uint64), np.arange(3, dtype=np.uint64), 2)[0] == 2
