@@ -192,29 +192,42 @@ __device__ __forceinline__ void cg_row_cached(RowEval<T, NC, SL, NW>& ev, const 
     PMF_EW { gp[i] = (T)0; dp[i] = (T)0; dummy[i] = (T)0; }
     T gprev_sq = (T)0;
 
-    // f0 = f(x), keeping p = T.x                                              ref: src/nonnegcg.c:191
+    // f0 = f(x) and the first gradient from ONE pass over the row (both are evaluated at x; the reference computes
+    // f0 first, ref: src/nonnegcg.c:191, and returns before the gradient if it is not finite -- same outcome), keeping
+    // p = T.x on the way
     ev.set_point(x);
     T reg = ev.dot(bsum, x);
     reg += P.l2 * ev.dot(x, x);
-    T f_cur = reg - (T)ev.template eval<true, false>((T)0, dummy, ev.pbuf) * P.w;
+    if (!weighted) { PMF_EW g[i] = fma_t(two_l2, x[i], bsum[i]); }
+    else { PMF_EW g[i] = (T)0; }
+    T f_cur = reg - (T)ev.template eval<true, true>((T)-1, g, ev.pbuf) * P.w;
+    if (weighted) {
+        PMF_EW {
+            g[i] = g[i] * P.w;
+            g[i] = g[i] + bsum[i];
+            g[i] = fma_t(two_l2, x[i], g[i]);
+        }
+    }
     T f_new = (T)0;
     int nfeval = 1;
     if (not_finite(f_cur)) return;
-    bool p_fresh = true;  // pbuf == T.x exactly (just computed) rather than advanced by p += alpha q
 
     for (int it = 0; it < maxiter; it++) {
-        // gradient at x; the same pass refreshes p = T.x unless it is already exact
-        ev.set_point(x);
-        if (!weighted) {
-            PMF_EW g[i] = fma_t(two_l2, x[i], bsum[i]);
-            ev.template eval<false, true>((T)-1, g, p_fresh ? nullptr : ev.pbuf);
-        } else {
-            PMF_EW g[i] = (T)0;
-            ev.template eval<false, true>((T)-1, g, p_fresh ? nullptr : ev.pbuf);
-            PMF_EW {
-                g[i] = g[i] * P.w;
-                g[i] = g[i] + bsum[i];
-                g[i] = fma_t(two_l2, x[i], g[i]);
+        if (it > 0) {
+            // gradient at x: coefficients from the cached p = T.x are not used -- the pass recomputes F_j . x (and
+            // refreshes p with the exact values, undoing the rounding of p += alpha q)
+            ev.set_point(x);
+            if (!weighted) {
+                PMF_EW g[i] = fma_t(two_l2, x[i], bsum[i]);
+                ev.template eval<false, true>((T)-1, g, ev.pbuf);
+            } else {
+                PMF_EW g[i] = (T)0;
+                ev.template eval<false, true>((T)-1, g, ev.pbuf);
+                PMF_EW {
+                    g[i] = g[i] * P.w;
+                    g[i] = g[i] + bsum[i];
+                    g[i] = fma_t(two_l2, x[i], g[i]);
+                }
             }
         }
         PMF_EW d[i] = (x[i] <= (T)0 && g[i] >= (T)0) ? (T)0 : -g[i];
@@ -261,7 +274,7 @@ __device__ __forceinline__ void cg_row_cached(RowEval<T, NC, SL, NW>& ev, const 
             if (nfeval >= maxnfeval) return;
             step *= decr;
         }
-        if (accepted) { ev.advance_cached(step); p_fresh = false; }
+        (void)accepted;  // p = T.x is recomputed exactly by the next gradient pass
         f_cur = f_new;
         gprev_sq = ev.dot(g, g);
         PMF_EW { gp[i] = g[i]; dp[i] = d[i]; }
