@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "poismf_hip.h")
 UNITS = {
-    "poismf_hip": ["poismf_hip.hip", "solvers.hpp", "row_eval.hpp", "wave_ops.hpp"],
+    "poismf_hip": ["poismf_hip.hip", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "wave_ops.hpp"],
     "coo_convert": ["coo_convert.hip"],
     "serve": ["serve.hip"],
 }

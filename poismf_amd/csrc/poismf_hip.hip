@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/poismf_hip.h"
+#include "reg_eval.hpp"
 #include "solvers.hpp"
 
 using namespace pmf;
@@ -44,16 +45,11 @@ template <class T> struct HalfArgs {
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
 
-// One wavefront (= one 64-thread workgroup, so no workgroup barrier is ever needed and the LDS tile
-// is private) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the nnz-sorted permutation.
-template <class T, int NC, int METHOD, int SL, int NW>
-__global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> a)
+// A wavefront (or, NW > 1, a workgroup of NW wavefronts) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the
+// nnz-sorted permutation, or pulls them from a device-wide queue.
+template <class EV, class T, int NC, int METHOD, int NW>
+__device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    RowEval<T, NC, SL, NW> ev;
-#ifdef PMF_TIMING
-    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
-#endif
     ev.init(a.geom, a.F, smem);
     const int k = a.geom.k;
     T bs[NC];
@@ -122,7 +118,7 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
             T prev[NC];
             PMF_EW prev[i] = x[i];
             if (!a.reuse_prev) { PMF_EW x[i] = (T)1e-3; }                   // ref: src/poismf.c:379-381
-            (void)Tnc<T, NC, SL, NW>::minimize(ev, a.P, shift, x);
+            (void)Tnc<T, NC, EV>::minimize(ev, a.P, shift, x);
             if (a.early_stop) {                                             // ref: src/poismf.c:393-396
                 PMF_EW prev[i] = prev[i] - x[i];
                 const T moved = ev.dot(prev, prev);
@@ -131,11 +127,36 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
         }
         ev.store_vec(out, x);
     }
+}
+
+// LDS-tile engine (row_eval.hpp): one wavefront (= one 64-thread workgroup, so no workgroup barrier is ever needed and
+// the LDS tile is private), or NW wavefronts per row for the long-row path.
+template <class T, int NC, int METHOD, int SL, int NW>
+__global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    RowEval<T, NC, SL, NW> ev;
+#ifdef PMF_TIMING
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
+    sweep_rows<RowEval<T, NC, SL, NW>, T, NC, METHOD, NW>(a, ev, smem);
 #ifdef PMF_TIMING
     ev.tacc[5] = __builtin_amdgcn_s_memtime() - t_kernel;
     if (ev.lane == 0 && ev.wid == 0)
         for (int q = 0; q < 6; q++) atomicAdd(&g_pmf_timing[q], ev.tacc[q]);
 #endif
+}
+
+// waves per SIMD the register allocator is asked to make room for: 512 VGPRs / (tile 4 S + ~44 working registers)
+#ifndef REG_WAVES
+#define REG_WAVES(S) ((S) <= 4 ? 8 : (S) <= 8 ? 6 : (S) <= 12 ? 5 : (S) <= 16 ? 4 : (S) <= 28 ? 3 : 2)
+#endif
+// Register-tile engine (reg_eval.hpp) for rows of at most 4 S nonzeros: no LDS at all, waves per CU set by VGPRs.
+template <class T, int METHOD, int S>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REG_WAVES(S)))) void half_sweep_reg_kernel(const HalfArgs<T> a)
+{
+    RegEval<T, S> ev;
+    sweep_rows<RegEval<T, S>, T, RegEval<T, S>::NC, METHOD, 1>(a, ev, nullptr);
 }
 
 // ---- column sums of a dense [n x k] factor: sum_by_cols, ref: src/poismf.c:77-83 ---------------------
@@ -379,6 +400,59 @@ template <int NC, int SL, int NW = 1> int launch_method(hipStream_t stream, int 
     }
 }
 
+// ---- register-tile engine (reg_eval.hpp) ---------------------------------------------------------------------------
+// Tile steps S (4 nonzeros each) with an instantiated kernel; a bin takes the smallest S that covers its longest row.
+constexpr int REG_S[] = { 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48 };
+constexpr int REG_S_MAX = 48;
+int reg_steps_for(unsigned max_nnz)
+{
+    for (int s : REG_S)
+        if ((unsigned)(4 * s) >= max_nnz) return s;
+    return 0;
+}
+
+template <int METHOD, int S> int launch_reg(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    auto kern = half_sweep_reg_kernel<real_t, METHOD, S>;
+    static int occ = 0;  // waves per CU the register budget of this instance allows
+    if (occ == 0) {
+        int n = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), WAVE, 0));
+        occ = std::max(1, n);
+    }
+    const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)NUM_CU * (size_t)occ * grid_mult);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int S> int launch_reg_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    switch (method) {
+        case POISMF_PG: return launch_reg<K_PG, S>(stream, a, grid_mult);
+        default: return 1;
+    }
+}
+
+int launch_reg_steps(hipStream_t stream, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    switch (S) {
+        case 4: return launch_reg_method<4>(stream, method, a, grid_mult);
+        case 8: return launch_reg_method<8>(stream, method, a, grid_mult);
+        case 12: return launch_reg_method<12>(stream, method, a, grid_mult);
+        case 16: return launch_reg_method<16>(stream, method, a, grid_mult);
+        case 20: return launch_reg_method<20>(stream, method, a, grid_mult);
+        case 24: return launch_reg_method<24>(stream, method, a, grid_mult);
+        case 28: return launch_reg_method<28>(stream, method, a, grid_mult);
+        case 32: return launch_reg_method<32>(stream, method, a, grid_mult);
+        case 36: return launch_reg_method<36>(stream, method, a, grid_mult);
+        case 40: return launch_reg_method<40>(stream, method, a, grid_mult);
+        case 48: return launch_reg_method<48>(stream, method, a, grid_mult);
+    }
+    return 1;
+}
+bool reg_engine_supports(int method) { return method == POISMF_PG; }
+
 // Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
 constexpr unsigned LONG_ROW_NNZ = 8192;
 constexpr int LONG_NW = 8;
@@ -449,7 +523,9 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
     }
     s->dimA = dimA; s->dimB = dimB; s->k = k;
     auto fail = [&]() { poismf_hip_session_destroy(s); return 1; };
-    const size_t slack = 16;
+    // behind each factor: one all-zero row (the register engine points the unused steps of a row at it) + 16 B so that
+    // the last 16-byte slot of the last row stays in bounds
+    const size_t slack = k * sizeof(real_t) + 16;
     if (hipMalloc(&s->dA, dimA * k * sizeof(real_t) + slack) != hipSuccess) return fail();
     if (hipMalloc(&s->dB, dimB * k * sizeof(real_t) + slack) != hipSuccess) return fail();
     if (hipMemsetAsync(s->dA, 0, dimA * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
@@ -605,14 +681,27 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
     // solver) are merged into one launch.
-    struct Launch { unsigned begin, count; TileGeom geom; int nw; };
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; };
     std::vector<Launch> launches;
+    static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
+    // register engine: factor rows of at most 16 slots, and 24-bit row ids / 32-bit byte offsets into the factor
+    const bool reg_ok = !no_reg && reg_engine_supports(p->method) && (s->k * sizeof(real_t) + 15) / 16 <= 16 &&
+                        dimF < ((size_t)1 << 24) && (dimF + 1) * s->k * sizeof(real_t) + 16 < ((size_t)1 << 32);
     static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
     if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
     for (const Bin& b : h.bins) {
         TileGeom g = plan_geom(s->k, b.max_nnz, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) g.resident = 0;  // one pass: "gather once" and "stream" are the same thing
+        if (reg_ok && b.max_nnz <= 4u * REG_S_MAX) {
+            // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
+            const int S = reg_steps_for(b.max_nnz);
+            if (!launches.empty() && launches.back().reg_S == S && launches.back().begin + launches.back().count == b.begin)
+                launches.back().count += b.count;
+            else
+                launches.push_back({ b.begin, b.count, g, 1, S });
+            continue;
+        }
         if (!no_long && b.max_nnz > long_thr) {
             // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
             // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
@@ -624,18 +713,18 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 if (cap <= 16 || lds_bytes_per_block(g, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
                 cap -= 16;
             }
-            if (!launches.empty() && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
+            if (!launches.empty() && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
                 launches.back().count += b.count;
             else
-                launches.push_back({ b.begin, b.count, g, LONG_NW });
+                launches.push_back({ b.begin, b.count, g, LONG_NW, 0 });
             continue;
         }
-        if (!launches.empty() && launches.back().geom.cap == g.cap && launches.back().geom.resident == g.resident &&
-            (g.resident == 0) && g.pq_cap == 0 && launches.back().geom.pq_cap == 0 && launches.back().nw == 1 &&
+        if (!launches.empty() && launches.back().reg_S == 0 && launches.back().geom.cap == g.cap &&
+            launches.back().geom.resident == g.resident && (g.resident == 0) && g.pq_cap == 0 && launches.back().geom.pq_cap == 0 && launches.back().nw == 1 &&
             launches.back().begin + launches.back().count == b.begin)
             launches.back().count += b.count;
         else
-            launches.push_back({ b.begin, b.count, g, 1 });
+            launches.push_back({ b.begin, b.count, g, 1, 0 });
     }
     static const bool static_rows = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;  // testing knob
     const bool dynamic = !is_pg && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
@@ -658,12 +747,17 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         a.perm_begin = L.begin;
         a.nrows = L.count;
         a.geom = L.geom;
+        a.geom.zero_row = (unsigned)dimF;
         const size_t lds = lds_bytes_per_block(a.geom, sizeof(real_t), L.nw);
         const unsigned waves_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / lds));
         unsigned grid_mult = 2;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)NUM_CU * waves_per_cu * grid_mult);
         int rc = 1;
+        if (L.reg_S > 0) {
+            if (launch_reg_steps(s->stream, L.reg_S, p->method, a, grid_mult)) return 1;
+            continue;
+        }
         if (L.nw > 1) {
             switch (slots_per_lane(s->k)) {
                 case 1: rc = launch_method<1 * SLOT_ELEMS, 0, LONG_NW>(long_stream, p->method, a, lds, grid); break;

@@ -59,6 +59,7 @@ struct TileGeom {
     int resident;  // 1: every row of this launch has nnz <= cap, gather once per row
     int group;     // G: lanes per vector copy (16, 32 or 64)
     int pq_cap;    // nonzeros for which the two per-nonzero prediction caches (T.x, T.d) fit in LDS; 0 = no cache
+    unsigned zero_row;  // index of the all-zero row the session keeps behind the factor F (= its row count)
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t sizeof_real)

@@ -32,8 +32,8 @@ template <class T> struct RowParams {
 // ------------------------------------------------------------------------------------------------
 // Proximal gradient
 // ------------------------------------------------------------------------------------------------
-template <class T, int NC, int SL, int NW>
-__device__ __forceinline__ void pg_row(RowEval<T, NC, SL, NW>& ev, const RowParams<T>& P, T (&x)[NC], const T (&shift)[NC])
+template <class EV, class T, int NC>
+__device__ __forceinline__ void pg_row(EV& ev, const RowParams<T>& P, T (&x)[NC], const T (&shift)[NC])
 {
     for (int u = 0; u < P.maxupd; u++) {
         ev.set_point(x);
@@ -53,8 +53,8 @@ __device__ __forceinline__ void pg_row(RowEval<T, NC, SL, NW>& ev, const RowPara
 // Objective / gradient wrappers on top of RowEval
 // ------------------------------------------------------------------------------------------------
 // f = bsum.a + l2 (a.a) - w sum x log(a.F_j)                     ref: src/poismf.c:194-208
-template <class T, int NC, int SL, int NW>
-__device__ __forceinline__ T fun_single(RowEval<T, NC, SL, NW>& ev, const RowParams<T>& P, const T (&bsum)[NC], const T (&a)[NC])
+template <class EV, class T, int NC>
+__device__ __forceinline__ T fun_single(EV& ev, const RowParams<T>& P, const T (&bsum)[NC], const T (&a)[NC])
 {
     ev.set_point(a);
     T dummy[NC];
@@ -67,8 +67,8 @@ __device__ __forceinline__ T fun_single(RowEval<T, NC, SL, NW>& ev, const RowPar
 
 // w == 1: g = bsum + 2 l2 a - sum (x/(a.F_j)) F_j                 ref: src/poismf.c:210-223
 // w != 1: g = w (-sum ...) + bsum_row + 2 l2 a                    ref: src/poismf.c:225-240 (quirk Q11)
-template <class T, int NC, int SL, int NW>
-__device__ __forceinline__ void grad_single(RowEval<T, NC, SL, NW>& ev, const RowParams<T>& P, const T (&bsum)[NC],
+template <class EV, class T, int NC>
+__device__ __forceinline__ void grad_single(EV& ev, const RowParams<T>& P, const T (&bsum)[NC],
                                             const T (&a)[NC], T (&g)[NC], bool weighted)
 {
     ev.set_point(a);
@@ -88,8 +88,8 @@ __device__ __forceinline__ void grad_single(RowEval<T, NC, SL, NW>& ev, const Ro
 }
 
 // fused f and g for TNC; f omits the l2 term (quirk Q4)           ref: src/poismf.c:242-273
-template <class T, int NC, int SL, int NW>
-__device__ __forceinline__ T fun_and_grad(RowEval<T, NC, SL, NW>& ev, const RowParams<T>& P, const T (&bsum)[NC],
+template <class EV, class T, int NC>
+__device__ __forceinline__ T fun_and_grad(EV& ev, const RowParams<T>& P, const T (&bsum)[NC],
                                           const T (&a)[NC], T (&g)[NC])
 {
     ev.set_point(a);
@@ -106,8 +106,8 @@ __device__ __forceinline__ T fun_and_grad(RowEval<T, NC, SL, NW>& ev, const RowP
 // ------------------------------------------------------------------------------------------------
 // Non-negative Polak-Ribiere CG (Li 2013)                        ref: src/nonnegcg.c:177-346
 // ------------------------------------------------------------------------------------------------
-template <class T, int NC, int SL, int NW>
-__device__ __forceinline__ void cg_row(RowEval<T, NC, SL, NW>& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC],
+template <class EV, class T, int NC>
+__device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC],
                                        bool weighted)
 {
     const T tol = (T)1e-2, decr = (T)0.25, c_ls = (T)0.01;         // ref: src/poismf.c:318-319
@@ -180,8 +180,8 @@ __device__ __forceinline__ void cg_row(RowEval<T, NC, SL, NW>& ev, const RowPara
 // x with p = T.x stored on the way, then q = T.d) and every Armijo trial costs nnz fused-multiply-adds and logs
 // instead of another pass over the tile -- for rows that do not fit in LDS that is 2 gathers per iteration
 // instead of ~6.  Arithmetic differs from the direct evaluation by rounding only (p + alpha q vs a fresh dot).
-template <class T, int NC, int SL, int NW>
-__device__ __forceinline__ void cg_row_cached(RowEval<T, NC, SL, NW>& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC],
+template <class EV, class T, int NC>
+__device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC],
                                               bool weighted)
 {
     const T tol = (T)1e-2, decr = (T)0.25, c_ls = (T)0.01;
@@ -467,8 +467,7 @@ template <class T, int NC> struct TncState {
     int nfeval, maxnfeval;
 };
 
-template <class T, int NC, int SL, int NW> struct Tnc {
-    using EV = RowEval<T, NC, SL, NW>;
+template <class T, int NC, class EV> struct Tnc {
     using ST = TncState<T, NC>;
     static constexpr T EPSV = Eps<T>::v;
 
