@@ -147,16 +147,17 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
 #endif
 }
 
-// waves per SIMD the register allocator is asked to make room for: 512 VGPRs / (tile 4 S + ~44 working registers)
+// waves per SIMD the register allocator is asked to make room for, by tile registers TR = 4 S NS (512 VGPRs per
+// SIMD lane; the solvers' working set comes on top)
 #ifndef REG_WAVES
-#define REG_WAVES(S) ((S) <= 4 ? 8 : (S) <= 8 ? 6 : (S) <= 12 ? 5 : (S) <= 16 ? 4 : (S) <= 28 ? 3 : 2)
+#define REG_WAVES(TR) ((TR) <= 16 ? 6 : (TR) <= 32 ? 5 : (TR) <= 64 ? 4 : (TR) <= 112 ? 3 : 2)
 #endif
-// Register-tile engine (reg_eval.hpp) for rows of at most 4 S nonzeros: no LDS at all, waves per CU set by VGPRs.
-template <class T, int METHOD, int S>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REG_WAVES(S)))) void half_sweep_reg_kernel(const HalfArgs<T> a)
+// Register-tile engine (reg_eval.hpp) for rows of at most (64 / G) S nonzeros: no LDS at all, waves per CU set by VGPRs.
+template <class T, int METHOD, int S, int G, int NS>
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REG_WAVES(4 * S * NS)))) void half_sweep_reg_kernel(const HalfArgs<T> a)
 {
-    RegEval<T, S> ev;
-    sweep_rows<RegEval<T, S>, T, RegEval<T, S>::NC, METHOD, 1>(a, ev, nullptr);
+    RegEval<T, S, G, NS> ev;
+    sweep_rows<RegEval<T, S, G, NS>, T, RegEval<T, S, G, NS>::NC, METHOD, 1>(a, ev, nullptr);
 }
 
 // ---- column sums of a dense [n x k] factor: sum_by_cols, ref: src/poismf.c:77-83 ---------------------
@@ -401,19 +402,27 @@ template <int NC, int SL, int NW = 1> int launch_method(hipStream_t stream, int 
 }
 
 // ---- register-tile engine (reg_eval.hpp) ---------------------------------------------------------------------------
-// Tile steps S (4 nonzeros each) with an instantiated kernel; a bin takes the smallest S that covers its longest row.
-constexpr int REG_S[] = { 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48 };
-constexpr int REG_S_MAX = 48;
+// A factor row is held by REG_G lanes (NS = 1 or 2 slots per lane); a step covers 64 / REG_G nonzeros.  Tile steps S
+// with an instantiated kernel; a bin takes the smallest S that covers its longest row.
+#ifndef PMF_REG_G
+#define PMF_REG_G 16
+#endif
+constexpr int REG_G = PMF_REG_G;
+constexpr int REG_JG = WAVE / REG_G;
+// tile sizes in nonzeros with an instantiated kernel (S = nonzeros / REG_JG steps)
+#define PMF_REG_SIZES(X) X(16) X(32) X(48) X(64) X(80) X(96) X(112) X(128) X(144) X(160)
+constexpr int REG_NNZ_MAX = 160;
 int reg_steps_for(unsigned max_nnz)
 {
-    for (int s : REG_S)
-        if ((unsigned)(4 * s) >= max_nnz) return s;
+#define X(NZ) if ((unsigned)(NZ) >= max_nnz) return (NZ) / REG_JG;
+    PMF_REG_SIZES(X)
+#undef X
     return 0;
 }
 
-template <int METHOD, int S> int launch_reg(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD, int S, int NS> int launch_reg(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
-    auto kern = half_sweep_reg_kernel<real_t, METHOD, S>;
+    auto kern = half_sweep_reg_kernel<real_t, METHOD, S, REG_G, NS>;
     static int occ = 0;  // waves per CU the register budget of this instance allows
     if (occ == 0) {
         int n = 0;
@@ -426,28 +435,20 @@ template <int METHOD, int S> int launch_reg(hipStream_t stream, const HalfArgs<r
     return 0;
 }
 
-template <int S> int launch_reg_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int S, int NS> int launch_reg_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     switch (method) {
-        case POISMF_PG: return launch_reg<K_PG, S>(stream, a, grid_mult);
+        case POISMF_PG: return launch_reg<K_PG, S, NS>(stream, a, grid_mult);
         default: return 1;
     }
 }
 
-int launch_reg_steps(hipStream_t stream, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int NS> int launch_reg_steps(hipStream_t stream, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     switch (S) {
-        case 4: return launch_reg_method<4>(stream, method, a, grid_mult);
-        case 8: return launch_reg_method<8>(stream, method, a, grid_mult);
-        case 12: return launch_reg_method<12>(stream, method, a, grid_mult);
-        case 16: return launch_reg_method<16>(stream, method, a, grid_mult);
-        case 20: return launch_reg_method<20>(stream, method, a, grid_mult);
-        case 24: return launch_reg_method<24>(stream, method, a, grid_mult);
-        case 28: return launch_reg_method<28>(stream, method, a, grid_mult);
-        case 32: return launch_reg_method<32>(stream, method, a, grid_mult);
-        case 36: return launch_reg_method<36>(stream, method, a, grid_mult);
-        case 40: return launch_reg_method<40>(stream, method, a, grid_mult);
-        case 48: return launch_reg_method<48>(stream, method, a, grid_mult);
+#define X(NZ) case (NZ) / REG_JG: return launch_reg_method<(NZ) / REG_JG, NS>(stream, method, a, grid_mult);
+        PMF_REG_SIZES(X)
+#undef X
     }
     return 1;
 }
@@ -693,7 +694,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     for (const Bin& b : h.bins) {
         TileGeom g = plan_geom(s->k, b.max_nnz, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) g.resident = 0;  // one pass: "gather once" and "stream" are the same thing
-        if (reg_ok && b.max_nnz <= 4u * REG_S_MAX) {
+        if (reg_ok && b.max_nnz <= (unsigned)REG_NNZ_MAX) {
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
             const int S = reg_steps_for(b.max_nnz);
             if (!launches.empty() && launches.back().reg_S == S && launches.back().begin + launches.back().count == b.begin)
@@ -731,11 +732,12 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     if (dynamic) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
     // the few workgroup-per-row launches of the power-law tail occupy a few dozen CUs for a long time: run them on a
     // second stream beside the other bins (fork after the column sums, join before anything reads the result)
+    // Several launches per half: they also alternate between the two streams (each to the one with less work queued so
+    // far), so that the tail of one bin overlaps the start of the next.
     static const bool no_fork = getenv("POISMF_HIP_NO_FORK") != nullptr;  // testing knob
-    bool forked = false;
-    for (const Launch& L : launches) forked = forked || L.nw > 1;
-    forked = forked && !no_fork;
+    bool forked = launches.size() > 1 && !no_fork;
     hipStream_t long_stream = forked ? s->aux_stream : s->stream;
+    double queued[2] = { 0.0, 0.0 };
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
         HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
@@ -754,8 +756,15 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)NUM_CU * waves_per_cu * grid_mult);
         int rc = 1;
+        const int lane_stream = (forked && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
+        hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
+        queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         if (L.reg_S > 0) {
-            if (launch_reg_steps(s->stream, L.reg_S, p->method, a, grid_mult)) return 1;
+            int rrc;
+            if constexpr (REG_G == 16) rrc = launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult);
+            else rrc = a.geom.s_load <= REG_G ? launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult)
+                                              : launch_reg_steps<2>(bin_stream, L.reg_S, p->method, a, grid_mult);
+            if (rrc) return 1;
             continue;
         }
         if (L.nw > 1) {
@@ -767,11 +776,11 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             continue;
         }
         static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
-        if (!generic_only && a.geom.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A>(s->stream, p->method, a, lds, grid);
-        else if (!generic_only && a.geom.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B>(s->stream, p->method, a, lds, grid);
+        if (!generic_only && a.geom.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A>(bin_stream, p->method, a, lds, grid);
+        else if (!generic_only && a.geom.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B>(bin_stream, p->method, a, lds, grid);
         else switch (slots_per_lane(s->k)) {
-            case 1: rc = launch_method<1 * SLOT_ELEMS, 0>(s->stream, p->method, a, lds, grid); break;
-            case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(s->stream, p->method, a, lds, grid); break;
+            case 1: rc = launch_method<1 * SLOT_ELEMS, 0>(bin_stream, p->method, a, lds, grid); break;
+            case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(bin_stream, p->method, a, lds, grid); break;
         }
         if (rc) return 1;
     }

@@ -2,21 +2,22 @@
 //
 // Same contract as RowEval (row_eval.hpp): one wavefront owns one output row, the factor rows F[ind_j] named by the
 // row's nonzeros are fetched once and every inner pass of the solver runs on chip.  Here "on chip" is the vector
-// register file instead of LDS: for rows of up to 4*S nonzeros whose factor rows fit 16 slots of 16 bytes (fp32
-// k <= 64, fp64 k <= 32) the whole tile is S slots per lane (k = 50 fp32, 100 nonzeros: 100 VGPRs), there is no LDS
-// traffic for the tile at all, and the waves per CU are set by registers (10-16) instead of by a 20-40 KiB LDS tile
-// (4-7).  Both phases of an evaluation work on ONE layout, the slot layout the solvers keep their k-vectors in:
+// register file instead of LDS: for rows of up to JG*S nonzeros whose factor rows fit 16 slots of 16 bytes (fp32
+// k <= 64, fp64 k <= 32) the whole tile is S*NS slots per lane (k = 50 fp32, 100 nonzeros: ~100 VGPRs), there is no
+// LDS traffic for the tile at all, and the waves per CU are set by registers (8-16) instead of by a 20-40 KiB LDS
+// tile (4-7).  Both phases of an evaluation work on ONE layout, the slot layout the solvers keep their k-vectors in:
 //
-//   lane = (jg, g): jg = lane / 16 is the DPP row, g = lane % 16 the 16-byte slot of a factor row;
-//   step s (0 <= s < S) handles the four nonzeros j = 4 s + jg, one per DPP row; t[s] is slot g of F[ind_j].
+//   lane = (jg, g): g = lane % G, jg = lane / G; a group of G (8 or 16) lanes holds one factor row, lane g its
+//   16-byte slots g, g + G, .. (NS per lane); the wave holds JG = 64 / G groups;
+//   step s (0 <= s < S) handles the JG nonzeros j = JG s + jg, one per group; t[s][n] is slot g + G n of F[ind_j].
 //
-//   dots     pred_j = F[ind_j] . a : every lane multiplies its slot of t[s] with its slot of `a` (2 packed FMAs), and
-//            the 16 lane-partials of a step are summed over the row.  Sixteen steps are reduced TOGETHER by a
-//            transposing butterfly (4 levels: 8 + 4 + 2 + 1 select-and-add pairs instead of 16 x 4 DPP adds) that
-//            leaves the finished pred of step 16 b + g in lane g -- 64 distinct nonzeros in 64 lanes, so the division
+//   dots     pred_j = F[ind_j] . a : every lane multiplies its slots of t[s] with its slots of `a` (packed FMAs), and
+//            the G lane-partials of a step are summed over the group.  G steps are reduced TOGETHER by a transposing
+//            butterfly (log2 G levels of select-and-add pairs: G - 1 folds instead of G log2 G DPP adds) that leaves
+//            the finished pred of step G b + g in lane g -- 64 distinct nonzeros in 64 lanes, so the division
 //            x_j / pred_j (and the double-precision log) is done exactly once per nonzero;
-//   axpy     acc += coef_j * t[s] for s in step order: coef of step u comes from lane u of the row by ds_swizzle (the
-//            LDS crossbar, no LDS memory), 2 packed FMAs per step; the four rows' partial sums are combined once per
+//   axpy     acc += coef_j * t[s] for s in step order: coef of step u comes from lane u of the group by ds_swizzle
+//            (the LDS crossbar, no LDS memory), packed FMAs; the JG groups' partial sums are combined once per
 //            evaluation.  Nonzero -> group assignment and summation order are those of RowEval's phase 2.
 //
 // This is the reference's per-nonzero ddot + daxpy (ref: src/poismf.c:126-133 calc_grad_pgd, :194-208
@@ -36,18 +37,22 @@ template <int I, int N, class Fn> __device__ __forceinline__ void static_for(Fn&
     }
 }
 
-// value of lane U of the caller's 16-lane row (ds_swizzle, bit-mask mode: src = (lane & 0x10) | U inside each half-wave)
-template <int U> __device__ __forceinline__ int row_bcast_i32(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x10 | (U << 5)); }
-template <int U> __device__ __forceinline__ unsigned row_bcast(unsigned v) { return (unsigned)row_bcast_i32<U>((int)v); }
-template <int U> __device__ __forceinline__ float row_bcast(float v)
+// value of lane U of the caller's group of G lanes (ds_swizzle, bit-mask mode inside each half-wave:
+// src = (lane & ~(G - 1)) | U)
+template <int G, int U> __device__ __forceinline__ int group_bcast_i32(int v)
 {
-    return __builtin_bit_cast(float, row_bcast_i32<U>(__builtin_bit_cast(int, v)));
+    return __builtin_amdgcn_ds_swizzle(v, (0x1f & ~(G - 1)) | (U << 5));
 }
-template <int U> __device__ __forceinline__ double row_bcast(double v)
+template <int G, int U> __device__ __forceinline__ unsigned group_bcast(unsigned v) { return (unsigned)group_bcast_i32<G, U>((int)v); }
+template <int G, int U> __device__ __forceinline__ float group_bcast(float v)
+{
+    return __builtin_bit_cast(float, group_bcast_i32<G, U>(__builtin_bit_cast(int, v)));
+}
+template <int G, int U> __device__ __forceinline__ double group_bcast(double v)
 {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)row_bcast_i32<U>((int)(unsigned)b);
-    const unsigned hi = (unsigned)row_bcast_i32<U>((int)(unsigned)(b >> 32));
+    const unsigned lo = (unsigned)group_bcast_i32<G, U>((int)(unsigned)b);
+    const unsigned hi = (unsigned)group_bcast_i32<G, U>((int)(unsigned)(b >> 32));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
@@ -62,28 +67,54 @@ template <int CTRL, class T> __device__ __forceinline__ T fold_pair(bool cls, T 
 }
 template <int CTRL, class T> __device__ __forceinline__ T fold_one(T pa) { return pa + dpp_mov<CTRL>(pa); }
 
-template <class T, int S> struct RegEval {
+// NIN (<= 2 H) inputs -> H outputs (output i collects input i in lanes of class 0 and input i + H in lanes of class 1)
+template <int CTRL, int H, int NIN, class T> __device__ __forceinline__ void fold_level(bool cls, const T* in, T* out)
+{
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+        if (i + H < NIN) out[i] = fold_pair<CTRL>(cls, in[i], in[i + H]);
+        else if (i < NIN) out[i] = fold_one<CTRL>(in[i]);
+        else out[i] = (T)0;
+    }
+}
+
+// num / den for the gradient coefficients.  fp32: reciprocal + one Newton step on the quotient + v_div_fixup (exact
+// handling of 0, inf and NaN operands) -- 5 instructions instead of the 14 of the IEEE sequence, within 1 ulp of it
+// (the tolerance of every fp32 comparison in tests/ is >= 1e-5).  fp64: IEEE division.
+__device__ __forceinline__ float coef_div(float num, float den)
+{
+    const float r = __builtin_amdgcn_rcpf(den);
+    float q = num * r;
+    const float e = __builtin_fmaf(-den, q, num);
+    q = __builtin_fmaf(e, r, q);
+    return __builtin_amdgcn_div_fixupf(q, den, num);
+}
+__device__ __forceinline__ double coef_div(double num, double den) { return num / den; }
+
+template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
-    static constexpr int NC = SN;                 // one 16-byte slot per lane
-    static constexpr int G = 16, JG = 4;
-    static constexpr int NB = (S + 15) / 16;      // batches of 16 steps = 64 nonzeros
+    static constexpr int G = G_, NS = NS_;
+    static constexpr int JG = WAVE / G;           // nonzeros per step
+    static constexpr int NC = NS * SN;            // elements per lane
+    static constexpr int NB = (S + G - 1) / G;    // batches of G steps = 64 nonzeros
     static constexpr int NW = 1;
+    static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
 
-    SA t[S];        // the tile
-    T a[NC];        // current point (this lane's slot)
-    T xr[NB];       // x_j of the nonzero whose pred this lane finishes in batch b: j = 64 b + 4 g + jg
+    SA t[S][NS];    // the tile
+    T a[NC];        // current point (this lane's slots)
+    T xr[NB];       // x_j of the nonzero whose pred this lane finishes in batch b: j = 64 b + JG g + jg
     // launch constants
     const T* F;
     unsigned zero_row;
     int k, s_load, tail;
     int lane, g, jg, wid;
-    int jlane;      // 4 g + jg
+    int jlane;      // JG g + jg
     bool cls8, cls4, cls2, cls1;
     int elem[NC];
     bool act[NC];
-    bool slot_on, slot_last;
+    bool slot_on[NS], slot_last[NS];
     unsigned nnz;
     // interface parity with RowEval (the cached line search is for streamed rows only)
     int pq_cap;
@@ -95,27 +126,31 @@ template <class T, int S> struct RegEval {
         lane = lane_id();
         F = F_;
         k = geo.k; s_load = geo.s_load; zero_row = geo.zero_row;
-        g = lane & 15; jg = lane >> 4; wid = 0;
-        jlane = 4 * g + jg;
+        g = lane & (G - 1); jg = lane / G; wid = 0;
+        jlane = JG * g + jg;
         cls8 = (lane & 8) != 0; cls4 = (lane & 4) != 0; cls2 = (lane & 2) != 0; cls1 = (lane & 1) != 0;
         tail = k - (s_load - 1) * SN;
-        slot_on = g < s_load;
-        slot_last = g == s_load - 1;
 #pragma unroll
-        for (int e = 0; e < SN; e++) {
-            elem[e] = g * SN + e;
-            act[e] = g * SN + e < k;
+        for (int n = 0; n < NS; n++) {
+            const int q = g + G * n;
+            slot_on[n] = q < s_load;
+            slot_last[n] = q == s_load - 1;
+#pragma unroll
+            for (int e = 0; e < SN; e++) {
+                elem[n * SN + e] = q * SN + e;
+                act[n * SN + e] = q * SN + e < k;
+            }
         }
         pq_cap = 0; pbuf = nullptr; qbuf = nullptr;
     }
 
-    // ---- k-length vector helpers (same slot layout as RowEval with G = 16) ----------------------------
+    // ---- k-length vector helpers (the slot layout of RowEval, with G = 8 as well) ----------------------
     template <class Op, class V> __device__ __forceinline__ V reduce(V x) const
     {
         x = Op::f(x, dpp_mov<0xB1>(x));
         x = Op::f(x, dpp_mov<0x4E>(x));
         x = Op::f(x, dpp_mov<0x141>(x));
-        x = Op::f(x, dpp_mov<0x140>(x));
+        if constexpr (G == 16) x = Op::f(x, dpp_mov<0x140>(x));
         return uniform(x);
     }
     template <class V> __device__ __forceinline__ V rsum(V x) const { return reduce<OpSum>(x); }
@@ -143,8 +178,8 @@ template <class T, int S> struct RegEval {
         }
     }
 
-    // ---- gather: indices / values coalesced in the "finishing lane" layout, then one 16-byte load per step ----
-    // All S loads of a row are issued back to back, unconditionally: steps past the end of the row and lanes whose
+    // ---- gather: indices / values coalesced in the "finishing lane" layout, then NS 16-byte loads per step ----
+    // All loads of a row are issued back to back, unconditionally: steps past the end of the row and lanes whose
     // slot does not exist fetch from row `zero_row` = dimF, an all-zero row the session keeps behind the factor, so
     // nothing needs masking afterwards except the excess of the last slot.
     __device__ __forceinline__ void begin_row(const unsigned* ind, const T* val, unsigned nnz_)
@@ -159,73 +194,86 @@ template <class T, int S> struct RegEval {
             xr[b] = ok ? val[j] : (T)0;
         }
         // byte offset of this lane's slot of factor row c: 24-bit multiply-add, 32-bit result (the host only takes
-        // this engine when the factor has < 2^24 rows and < 4 GiB, see reg_engine_fits).  Lanes whose slot does not
-        // exist read the first 16 bytes of the zero row instead.
+        // this engine when the factor has < 2^24 rows and < 4 GiB).  Lanes whose slot does not exist read the first
+        // 16 bytes of the zero row instead.
         const unsigned rowbytes = (unsigned)k * (unsigned)sizeof(T);
-        const unsigned lane_off = slot_on ? (unsigned)(g * 16) : 0u;
-        const bool cut = slot_last && tail < SN;  // the last slot of a factor row reads past its end: zero the excess
+        unsigned lane_off[NS];
+        bool cut[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            lane_off[n] = slot_on[n] ? (unsigned)((g + G * n) * 16) : 0u;
+            cut[n] = slot_last[n] && tail < SN;  // the last slot of a factor row reads past its end: zero the excess
+        }
         static_for<0, S>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            // index of nonzero 4 s + jg sits in lane s % 16 of row jg
-            const unsigned c = row_bcast<s % 16>(idx[s / 16]);
-            const unsigned off = __umul24(slot_on ? c : zero_row, rowbytes) + lane_off;
-            const SU v = *(const SU*)((const char*)F + (size_t)off);
-            t[s].v[0] = v.v[0];
+            // index of nonzero JG s + jg sits in lane s % G of group jg
+            const unsigned c = group_bcast<G, s % G>(idx[s / G]);
 #pragma unroll
-            for (int e = 1; e < SN; e++) t[s].v[e] = (cut && e >= tail) ? (T)0 : v.v[e];
+            for (int n = 0; n < NS; n++) {
+                const unsigned off = __umul24(slot_on[n] ? c : zero_row, rowbytes) + lane_off[n];
+                const SU v = *(const SU*)((const char*)F + (size_t)off);
+                t[s][n].v[0] = v.v[0];
+#pragma unroll
+                for (int e = 1; e < SN; e++) t[s][n].v[e] = (cut[n] && e >= tail) ? (T)0 : v.v[e];
+            }
         });
     }
 
     __device__ __forceinline__ void set_point(const T (&x)[NC])
     {
 #pragma unroll
-        for (int e = 0; e < SN; e++) a[e] = act[e] ? x[e] : (T)0;
+        for (int i = 0; i < NC; i++) a[i] = act[i] ? x[i] : (T)0;
     }
 
     // this lane's share of F[ind_j] . a for step s
-    __device__ __forceinline__ T lane_dot(const SA& w) const
+    __device__ __forceinline__ T lane_dot(const SA (&w)[NS]) const
     {
         if constexpr (SN == 4) {
             typedef T V2 __attribute__((ext_vector_type(2)));
-            V2 p = (V2){ w.v[0], w.v[1] } * (V2){ a[0], a[1] };
-            p = __builtin_elementwise_fma((V2){ w.v[2], w.v[3] }, (V2){ a[2], a[3] }, p);
+            V2 p = (V2){ w[0].v[0], w[0].v[1] } * (V2){ a[0], a[1] };
+            p = __builtin_elementwise_fma((V2){ w[0].v[2], w[0].v[3] }, (V2){ a[2], a[3] }, p);
+#pragma unroll
+            for (int n = 1; n < NS; n++) {
+                p = __builtin_elementwise_fma((V2){ w[n].v[0], w[n].v[1] }, (V2){ a[4 * n], a[4 * n + 1] }, p);
+                p = __builtin_elementwise_fma((V2){ w[n].v[2], w[n].v[3] }, (V2){ a[4 * n + 2], a[4 * n + 3] }, p);
+            }
             return p.x + p.y;
         } else {
-            return fma_t(w.v[1], a[1], w.v[0] * a[0]);
+            T p = fma_t(w[0].v[1], a[1], w[0].v[0] * a[0]);
+#pragma unroll
+            for (int n = 1; n < NS; n++) {
+                p = fma_t(w[n].v[0], a[2 * n], p);
+                p = fma_t(w[n].v[1], a[2 * n + 1], p);
+            }
+            return p;
         }
     }
 
-    // N (1..16) lane-partials p[u] -> lane g holds sum over its row of p[g] (lanes g >= N: unspecified)
-    template <int N> __device__ __forceinline__ T transpose_sum(const T (&p)[16]) const
+    // N (1..G) lane-partials p[u] -> lane g holds the sum over its group of p[g] (lanes g >= N: unspecified)
+    template <int N> __device__ __forceinline__ T transpose_sum(const T (&p)[G]) const
     {
         T q[8], r[4], s2[2];
+        constexpr int N8 = N < 8 ? N : 8;
+        if constexpr (G == 16) fold_level<0x128, 8, N>(cls8, p, q);               // row_ror:8           lane ^ 8
+        else {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (i + 8 < N) q[i] = fold_pair<0x128>(cls8, p[i], p[i + 8]);       // row_ror:8        lane ^ 8
-            else if (i < N) q[i] = fold_one<0x128>(p[i]);
-            else q[i] = (T)0;
+            for (int i = 0; i < 8; i++) q[i] = p[i];
         }
-        constexpr int NA = N < 8 ? N : 8;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (i + 4 < NA) r[i] = fold_pair<0x141>(cls4, q[i], q[i + 4]);      // row_half_mirror  lane ^ 7
-            else if (i < NA) r[i] = fold_one<0x141>(q[i]);
-            else r[i] = (T)0;
-        }
-        constexpr int NB_ = NA < 4 ? NA : 4;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            if (i + 2 < NB_) s2[i] = fold_pair<0x4E>(cls2, r[i], r[i + 2]);     // quad_perm[2,3,0,1]  lane ^ 2
-            else if (i < NB_) s2[i] = fold_one<0x4E>(r[i]);
-            else s2[i] = (T)0;
-        }
-        constexpr int NC_ = NB_ < 2 ? NB_ : 2;
-        if (NC_ == 2) return fold_pair<0xB1>(cls1, s2[0], s2[1]);               // quad_perm[1,0,3,2]  lane ^ 1
-        return fold_one<0xB1>(s2[0]);
+        fold_level<0x141, 4, N8>(cls4, q, r);                                      // row_half_mirror     lane ^ 7
+        constexpr int N4 = N8 < 4 ? N8 : 4;
+        fold_level<0x4E, 2, N4>(cls2, r, s2);                                      // quad_perm[2,3,0,1]  lane ^ 2
+        constexpr int N2 = N4 < 2 ? N4 : 2;
+        if constexpr (N2 == 2) return fold_pair<0xB1>(cls1, s2[0], s2[1]);        // quad_perm[1,0,3,2]  lane ^ 1
+        else return fold_one<0xB1>(s2[0]);
     }
 
+    // add up the JG groups' partial sums (every group ends with the total) and accumulate
     __device__ __forceinline__ void combine_groups(T (&part)[NC], T (&acc)[NC]) const
     {
+        if constexpr (G == 8) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) part[i] += dpp_mov<0x128>(part[i]);       // lane ^ 8
+        }
 #pragma unroll
         for (int i = 0; i < NC; i++) part[i] += __shfl_xor(part[i], 16);
 #pragma unroll
@@ -243,22 +291,24 @@ template <class T, int S> struct RegEval {
         for (int i = 0; i < NC; i++) part[i] = (T)0;
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            constexpr int n = (S - 16 * b) < 16 ? (S - 16 * b) : 16;
-            T p[16];
+            constexpr int n = (S - G * b) < G ? (S - G * b) : G;
+            T p[G];
 #pragma unroll
-            for (int u = 0; u < 16; u++) p[u] = u < n ? lane_dot(t[(16 * b + u) < S ? (16 * b + u) : 0]) : (T)0;
+            for (int u = 0; u < G; u++) p[u] = u < n ? lane_dot(t[(G * b + u) < S ? (G * b + u) : 0]) : (T)0;
             const T pred = transpose_sum<n>(p);
             const bool on = (unsigned)(64 * b + jlane) < nnz;
             const T xj = xr[b];
             if constexpr (WANT_F) lpart += on ? (double)xj * d_log((double)pred) : 0.0;
             if constexpr (WANT_G) {
-                const T coef = on ? sgn * xj / pred : (T)0;
+                const T coef = on ? coef_div(sgn * xj, pred) : (T)0;
                 static_for<0, n>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
-                    const T c = row_bcast<u>(coef);
-                    const SA& w = t[16 * b + u];
+                    const T c = group_bcast<G, u>(coef);
 #pragma unroll
-                    for (int e = 0; e < SN; e++) part[e] = fma_t(c, w.v[e], part[e]);
+                    for (int m = 0; m < NS; m++) {
+#pragma unroll
+                        for (int e = 0; e < SN; e++) part[m * SN + e] = fma_t(c, t[G * b + u][m].v[e], part[m * SN + e]);
+                    }
                 });
             }
         });
@@ -279,7 +329,10 @@ template <class T, int S> struct RegEval {
 #pragma unroll
         for (int s = 0; s < S; s++) {
 #pragma unroll
-            for (int e = 0; e < SN; e++) part[e] += t[s].v[e];   // slots of steps past the row's end are zero
+            for (int m = 0; m < NS; m++) {
+#pragma unroll
+                for (int e = 0; e < SN; e++) part[m * SN + e] += t[s][m].v[e];   // steps past the row's end hold zeros
+            }
         }
         combine_groups(part, acc);
     }
