@@ -141,7 +141,12 @@ POISMF_HIP_API void poismf_hip_session_destroy(poismf_hip_session *s);
 
 /* Device pointers to the session-owned, replicated factors: A is [dimA x k], B is [dimB x k],
  * row-major real_t (allocations carry 16 bytes of slack because rows are gathered in 16-byte
- * slots).  The caller may wrap them (e.g. as torch tensors) to run collectives on them. */
+ * slots).  The caller may wrap them (e.g. as torch tensors) to run collectives on them.
+ * For small k the session also keeps a line-padded copy of each factor for its gathers; a
+ * session whose shard is the whole factor refreshes that copy from its own row kernels and
+ * must be told about outside writes: call the getter again (or set_factors) after writing
+ * through a pointer obtained earlier.  Sessions with partial shards re-derive the copy from
+ * the compact factor before every half-sweep, so shard exchanges need no such call. */
 POISMF_HIP_API real_t *poismf_hip_session_A(poismf_hip_session *s);
 POISMF_HIP_API real_t *poismf_hip_session_B(poismf_hip_session *s);
 

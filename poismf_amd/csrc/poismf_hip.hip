@@ -28,6 +28,8 @@ using namespace pmf;
 // =================================================================================================
 template <class T> struct HalfArgs {
     T* M;                             // factor being updated, [dimM x k]
+    T* Mp;                            // its line-padded copy (row stride ldM), or nullptr: updated rows go to both
+    int ldM;
     const T* F;                       // opposing factor, [dimF x k] (+16 B of slack)
     const unsigned long long* indptr; // shard-local CSR row pointers (nrows_local + 1)
     const unsigned* indices;
@@ -83,10 +85,12 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
         const unsigned long long p0 = a.indptr[lrow], p1 = a.indptr[lrow + 1];
         const unsigned nnz = uniform((unsigned)(p1 - p0));
         T* out = a.M + (size_t)(a.row_offset + lrow) * (size_t)k;
+        T* out_p = a.Mp != nullptr ? a.Mp + (size_t)(a.row_offset + lrow) * (size_t)a.ldM : nullptr;
         T x[NC];
         if (nnz == 0) {  // rows without data are forced to zero every half (quirk Q7)
             PMF_EW x[i] = (T)0;
             ev.store_vec(out, x);
+            if (out_p != nullptr) ev.store_vec(out_p, x);
             continue;
         }
         ev.begin_row(a.indices + p0, a.values + p0, nnz);
@@ -126,6 +130,7 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
             }
         }
         ev.store_vec(out, x);
+        if (out_p != nullptr) ev.store_vec(out_p, x);
     }
 }
 
@@ -158,6 +163,17 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REG_WAVES(
 {
     RegEval<T, S, G, NS> ev;
     sweep_rows<RegEval<T, S, G, NS>, T, RegEval<T, S, G, NS>::NC, METHOD, 1>(a, ev, nullptr);
+}
+
+// ---- compact factor -> line-padded copy (the pad columns stay zero from the allocation) --------------------------
+template <class T> __global__ __launch_bounds__(256) void repad_kernel(const T* src, T* dst, size_t n, int k, int ld)
+{
+    const size_t total = n * (size_t)k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (size_t)k;
+        const int c = (int)(i - r * (size_t)k);
+        dst[r * (size_t)ld + c] = src[i];
+    }
 }
 
 // ---- column sums of a dense [n x k] factor: sum_by_cols, ref: src/poismf.c:77-83 ---------------------
@@ -269,6 +285,11 @@ struct poismf_hip_session {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t dimA = 0, dimB = 0, k = 0;
     real_t *dA = nullptr, *dB = nullptr;
+    // line-padded copies of the factors for the gathers (row stride `ld` elements = a multiple of 128 bytes), kept when
+    // that cuts the bytes a gathered row drags in by >= 10 %; refreshed from the compact factor before each half-sweep
+    real_t *dAp = nullptr, *dBp = nullptr;
+    size_t ld = 0;
+    bool padded_fresh[2] = { false, false };  // [0]: dBp mirrors dB, [1]: dAp mirrors dA
     Half half[2];  // [0]: rows of B (CSC), [1]: rows of A (CSR)
     real_t* d_bsum = nullptr;
     real_t* d_partial = nullptr;
@@ -531,6 +552,21 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
     if (hipMalloc(&s->dB, dimB * k * sizeof(real_t) + slack) != hipSuccess) return fail();
     if (hipMemsetAsync(s->dA, 0, dimA * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (hipMemsetAsync(s->dB, 0, dimB * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
+    {
+        // A gathered row of B bytes at an arbitrary 8-byte offset touches (B + 120) / 128 lines of 128 bytes on average;
+        // in a copy whose rows start on line boundaries it touches ceil(B / 128).  k = 50 fp32: 2.5 -> 2 lines.
+        const size_t rowb = k * sizeof(real_t);
+        const size_t padb = (rowb + 127) / 128 * 128;
+        static const bool no_pad = getenv("POISMF_HIP_NO_PAD") != nullptr;  // testing knob
+        if (!no_pad && padb != rowb && (double)padb <= 0.9 * (double)(rowb + 120)) {
+            s->ld = padb / sizeof(real_t);
+            const size_t pslack = padb + 16;
+            if (hipMalloc(&s->dAp, dimA * padb + pslack) != hipSuccess) return fail();
+            if (hipMalloc(&s->dBp, dimB * padb + pslack) != hipSuccess) return fail();
+            if (hipMemsetAsync(s->dAp, 0, dimA * padb + pslack, s->stream) != hipSuccess) return fail();
+            if (hipMemsetAsync(s->dBp, 0, dimB * padb + pslack, s->stream) != hipSuccess) return fail();
+        }
+    }
     if (hipMalloc(&s->d_bsum, k * sizeof(real_t) + slack) != hipSuccess) return fail();
     if (hipMalloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t)) != hipSuccess) return fail();
     if (hipMalloc(&s->d_counter, sizeof(unsigned)) != hipSuccess) return fail();
@@ -562,6 +598,8 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     free_half(s->half[1]);
     if (s->dA) (void)hipFree(s->dA);
     if (s->dB) (void)hipFree(s->dB);
+    if (s->dAp) (void)hipFree(s->dAp);
+    if (s->dBp) (void)hipFree(s->dBp);
     if (s->d_bsum) (void)hipFree(s->d_bsum);
     if (s->d_partial) (void)hipFree(s->d_partial);
     if (s->d_counter) (void)hipFree(s->d_counter);
@@ -569,8 +607,9 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     delete s;
 }
 
-real_t* poismf_hip_session_A(poismf_hip_session* s) { return s->dA; }
-real_t* poismf_hip_session_B(poismf_hip_session* s) { return s->dB; }
+// Whoever asks for the device pointers may write through them: the padded gather copies are re-derived afterwards.
+real_t* poismf_hip_session_A(poismf_hip_session* s) { s->padded_fresh[1] = false; return s->dA; }
+real_t* poismf_hip_session_B(poismf_hip_session* s) { s->padded_fresh[0] = false; return s->dB; }
 size_t poismf_hip_session_nnz(poismf_hip_session* s, int which) { return s->half[which ? 1 : 0].nnz; }
 
 #ifdef PMF_TIMING
@@ -590,6 +629,7 @@ int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, 
     HIP_TRY(hipMemcpyAsync(s->dA, A_host, s->dimA * s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->dB, B_host, s->dimB * s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    s->padded_fresh[0] = s->padded_fresh[1] = false;
     return 0;
 }
 
@@ -655,8 +695,30 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (colsum(s, F, dimF, p->l1_reg, neg_step, nscale)) return 1;
     }
 
+    // the gathers read the line-padded copy of the fixed factor when the session keeps one
+    const real_t* Fg = F;
+    size_t ldF = s->k;
+    real_t* Mp = nullptr;
+    if (s->ld != 0) {
+        // The padded copy of F is current only if this session's own previous half-sweep rewrote ALL of F (its row
+        // kernels store every updated row to both copies).  Anything else -- factors set by the caller, a shard
+        // exchange between GPUs writing into the compact factor -- is picked up by re-padding the whole factor.
+        real_t* Fp = which ? s->dBp : s->dAp;
+        if (!s->padded_fresh[which ? 0 : 1]) {
+            const size_t total = dimF * s->k;
+            const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)NUM_CU * 16);
+            if (blocks > 0) hipLaunchKernelGGL((repad_kernel<real_t>), dim3(blocks), dim3(256), 0, s->stream, F, Fp, dimF, (int)s->k, (int)s->ld);
+            HIP_TRY(hipGetLastError());
+        }
+        Fg = Fp;
+        ldF = s->ld;
+        Mp = which ? s->dAp : s->dBp;
+        s->padded_fresh[which ? 1 : 0] = h.row_begin == 0 && h.row_end == h.dimM;
+    }
+
     HalfArgs<real_t> a;
-    a.M = M; a.F = F;
+    a.M = M; a.F = Fg;
+    a.Mp = Mp; a.ldM = (int)s->ld;
     a.indptr = h.d_indptr; a.indices = h.d_indices; a.values = h.d_values; a.perm = h.d_perm;
     a.row_offset = (unsigned)h.row_begin;
     a.bsum = s->d_bsum;
@@ -687,7 +749,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots, and 24-bit row ids / 32-bit byte offsets into the factor
     const bool reg_ok = !no_reg && reg_engine_supports(p->method) && (s->k * sizeof(real_t) + 15) / 16 <= 16 &&
-                        dimF < ((size_t)1 << 24) && (dimF + 1) * s->k * sizeof(real_t) + 16 < ((size_t)1 << 32);
+                        dimF < ((size_t)1 << 24) && (dimF + 1) * ldF * sizeof(real_t) + 16 < ((size_t)1 << 32);
     static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
     if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
@@ -750,6 +812,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         a.nrows = L.count;
         a.geom = L.geom;
         a.geom.zero_row = (unsigned)dimF;
+        a.geom.ldF = (int)ldF;
         const size_t lds = lds_bytes_per_block(a.geom, sizeof(real_t), L.nw);
         const unsigned waves_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / lds));
         unsigned grid_mult = 2;

@@ -108,7 +108,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     // launch constants
     const T* F;
     unsigned zero_row;
-    int k, s_load, tail;
+    int k, ldF, s_load, tail;
     int lane, g, jg, wid;
     int jlane;      // JG g + jg
     bool cls8, cls4, cls2, cls1;
@@ -125,7 +125,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     {
         lane = lane_id();
         F = F_;
-        k = geo.k; s_load = geo.s_load; zero_row = geo.zero_row;
+        k = geo.k; ldF = geo.ldF; s_load = geo.s_load; zero_row = geo.zero_row;
         g = lane & (G - 1); jg = lane / G; wid = 0;
         jlane = JG * g + jg;
         cls8 = (lane & 8) != 0; cls4 = (lane & 4) != 0; cls2 = (lane & 2) != 0; cls1 = (lane & 1) != 0;
@@ -196,7 +196,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
         // byte offset of this lane's slot of factor row c: 24-bit multiply-add, 32-bit result (the host only takes
         // this engine when the factor has < 2^24 rows and < 4 GiB).  Lanes whose slot does not exist read the first
         // 16 bytes of the zero row instead.
-        const unsigned rowbytes = (unsigned)k * (unsigned)sizeof(T);
+        const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
         unsigned lane_off[NS];
         bool cut[NS];
 #pragma unroll

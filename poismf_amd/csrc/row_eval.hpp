@@ -60,6 +60,7 @@ struct TileGeom {
     int group;     // G: lanes per vector copy (16, 32 or 64)
     int pq_cap;    // nonzeros for which the two per-nonzero prediction caches (T.x, T.d) fit in LDS; 0 = no cache
     unsigned zero_row;  // index of the all-zero row the session keeps behind the factor F (= its row count)
+    int ldF;       // elements between consecutive rows of the gathered factor (k, or more in the line-padded copy)
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t sizeof_real)
@@ -116,7 +117,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     int wid;
     // launch constants
     const T* F;
-    int k, s_load, s_stride, cap, tail;
+    int k, ldF, s_load, s_stride, cap, tail;
     bool resident;
     int lane, G, JG, g, jg;
     int gj0, gt0, gdj, gdt;  // lane -> (nonzero, slot) walk of the gather, advanced 64 slots at a time
@@ -136,7 +137,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     {
         lane = lane_id();
         F = F_;
-        k = geo.k; cap = geo.cap; resident = geo.resident != 0;
+        k = geo.k; ldF = geo.ldF; cap = geo.cap; resident = geo.resident != 0;
         if constexpr (SL > 0) {  // compile-time geometry (the host only launches this instance when it matches)
             s_load = SL; s_stride = SL | 1; G = SL <= 16 ? 16 : (SL <= 32 ? 32 : 64);
         } else {
@@ -229,7 +230,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
             dst[u] = ok ? jr * s_stride + tr : -1;
             last[u] = tr == s_load - 1;
             const unsigned col = idxb[jr];
-            v[u] = *(const SU*)(F + (size_t)col * (size_t)k + (size_t)(tr * SN));
+            v[u] = *(const SU*)(F + (size_t)col * (size_t)ldF + (size_t)(tr * SN));
             t += gdt; j += gdj;
             if (t >= s_load) { t -= s_load; j += 1; }
         }
