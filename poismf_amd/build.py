@@ -35,6 +35,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
              "-Wno-pass-failed"]
+    flags += os.environ.get("POISMF_HIP_EXTRA_FLAGS", "").split()   # development: e.g. -DPMF_REG_G=8, -DPMF_TIMING
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     compiles = []

@@ -758,8 +758,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (single_pass) g.resident = 0;  // one pass: "gather once" and "stream" are the same thing
         if (reg_ok && b.max_nnz <= (unsigned)REG_NNZ_MAX) {
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
+            // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
             const int S = reg_steps_for(b.max_nnz);
-            if (!launches.empty() && launches.back().reg_S == S && launches.back().begin + launches.back().count == b.begin)
+            if (!launches.empty() && launches.back().reg_S >= S && (launches.back().reg_S == S || b.count < 4096u) &&
+                launches.back().begin + launches.back().count == b.begin)
                 launches.back().count += b.count;
             else
                 launches.push_back({ b.begin, b.count, g, 1, S });
@@ -796,8 +798,12 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // second stream beside the other bins (fork after the column sums, join before anything reads the result)
     // Several launches per half: they also alternate between the two streams (each to the one with less work queued so
     // far), so that the tail of one bin overlaps the start of the next.
+    // (off by default: overlapping launches make the per-kernel durations of a profile overlap too)
     static const bool no_fork = getenv("POISMF_HIP_NO_FORK") != nullptr;  // testing knob
-    bool forked = launches.size() > 1 && !no_fork;
+    static const bool fork_bins = getenv("POISMF_HIP_FORK_BINS") != nullptr;  // tuning knob
+    bool any_long = false;
+    for (const Launch& L : launches) any_long = any_long || L.nw > 1;
+    const bool forked = !no_fork && launches.size() > 1 && (any_long || fork_bins);
     hipStream_t long_stream = forked ? s->aux_stream : s->stream;
     double queued[2] = { 0.0, 0.0 };
     if (forked) {
@@ -819,7 +825,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)NUM_CU * waves_per_cu * grid_mult);
         int rc = 1;
-        const int lane_stream = (forked && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
+        const int lane_stream = (forked && fork_bins && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
         hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         if (L.reg_S > 0) {
