@@ -26,6 +26,7 @@ using namespace pmf;
 // =================================================================================================
 // Kernels
 // =================================================================================================
+struct RowDesc;
 template <class T> struct HalfArgs {
     T* M;                             // factor being updated, [dimM x k]
     T* Mp;                            // its line-padded copy (row stride ldM), or nullptr: updated rows go to both
@@ -35,6 +36,7 @@ template <class T> struct HalfArgs {
     const unsigned* indices;
     const T* values;
     const unsigned* perm;             // shard-local row ids, sorted by nnz descending
+    const struct RowDesc* desc;       // the same order, with each row's CSR offset and length (one load per row)
     unsigned perm_begin, nrows;       // this launch covers perm[perm_begin, perm_begin + nrows)
     unsigned row_offset;              // first global row of the shard (M row = row_offset + local id)
     const T* bsum;                    // k-vector: colsum(F) + l1 (pre-scaled for PG when w == 1)
@@ -47,90 +49,134 @@ template <class T> struct HalfArgs {
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
 
+// One row of the sorted order: where its nonzeros start in the shard's CSR arrays, how many, and which row it is.
+struct RowDesc { unsigned p0_lo, p0_hi, nnz, lrow; };
+
+// Everything after the row's tile has been requested: starting point, per-row constant term, inner solver, store.
+template <class EV, class T, int NC, int METHOD>
+__device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T (&bs)[NC], unsigned lrow, unsigned nnz)
+{
+    const int k = a.geom.k;
+    T* out = a.M + (size_t)(a.row_offset + lrow) * (size_t)k;
+    T* out_p = a.Mp != nullptr ? a.Mp + (size_t)(a.row_offset + lrow) * (size_t)a.ldM : nullptr;
+    T x[NC];
+    if (nnz == 0) {  // rows without data are forced to zero every half (quirk Q7)
+        PMF_EW x[i] = (T)0;
+        ev.store_vec(out, x);
+        if (out_p != nullptr) ev.store_vec(out_p, x);
+        return;
+    }
+    ev.load_vec(out, x);
+
+    // per-row constant term: the k-vector itself, or (w != 1) the reference's Bsum_w row
+    //   (w - 1) sum_j F_j + Bsum          ref: src/poismf.c:85-123 (adjustment_Bsum)
+    T shift[NC];
+    PMF_EW shift[i] = bs[i];
+    const bool weighted = a.P.w != (T)1;
+    if (weighted) {
+        T cs[NC];
+        PMF_EW cs[i] = (T)0;
+        ev.tile_colsum(cs);
+        const T wm1 = a.P.w - (T)1.;
+        PMF_EW {
+            shift[i] = cs[i] * wm1;
+            shift[i] = shift[i] + bs[i];
+        }
+        if (METHOD == K_PG) { PMF_EW shift[i] = shift[i] * a.P.neg_step; }  // dscal_large, ref: :526, :576
+    }
+
+    if constexpr (METHOD == K_PG) {
+        pg_row(ev, a.P, x, shift);
+    } else if constexpr (METHOD == K_CG) {
+        if (a.P.limit_step && ev.pq_cap > 0 && nnz <= (unsigned)ev.pq_cap) cg_row_cached(ev, a.P, shift, x, weighted);  // streamed rows only, see plan_geom
+        else cg_row(ev, a.P, shift, x, weighted);
+    } else {
+        T prev[NC];
+        PMF_EW prev[i] = x[i];
+        if (!a.reuse_prev) { PMF_EW x[i] = (T)1e-3; }                   // ref: src/poismf.c:379-381
+        (void)Tnc<T, NC, EV>::minimize(ev, a.P, shift, x);
+        if (a.early_stop) {                                             // ref: src/poismf.c:393-396
+            PMF_EW prev[i] = prev[i] - x[i];
+            const T moved = ev.dot(prev, prev);
+            if ((double)moved <= 1e-4 && ev.lane == 0 && ev.wid == 0) atomicAdd(a.n_unchanged, 1u);
+        }
+    }
+    ev.store_vec(out, x);
+    if (out_p != nullptr) ev.store_vec(out_p, x);
+}
+
 // A wavefront (or, NW > 1, a workgroup of NW wavefronts) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the
 // nnz-sorted permutation, or pulls them from a device-wide queue.
+//
+// Row hand-out.  PG does the same work for every nonzero, so the nnz-sorted rows are dealt out statically
+// (row r, r + grid, ...).  CG and TNCG take anything from a handful to ~400 evaluations per row: there rows are
+// pulled from a device-wide counter in nnz-descending order (longest first -- the GPU form of the reference's
+// `schedule(dynamic)`, ref: src/poismf.c:296, :352), one returning atomic per row.
 template <class EV, class T, int NC, int METHOD, int NW>
 __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
 {
     ev.init(a.geom, a.F, smem);
-    const int k = a.geom.k;
     T bs[NC];
     ev.load_vec(a.bsum, bs);
+    const RowDesc* desc = a.desc + a.perm_begin;
 
-    // Row hand-out.  PG does the same work for every nonzero, so the nnz-sorted rows are dealt out statically
-    // (row r, r + grid, ...).  CG and TNCG take anything from a handful to ~400 evaluations per row: there rows are
-    // pulled from a device-wide counter in nnz-descending order (longest first -- the GPU form of the reference's
-    // `schedule(dynamic)`, ref: src/poismf.c:296, :352), one returning atomic per row.
-    unsigned r = blockIdx.x;
-    for (;;) {
-        if (a.queue != nullptr) {
-            if constexpr (NW > 1) {
-                // broadcast through the last 16 bytes of the DYNAMIC LDS block (a static __shared__ object
-                // would shift the dynamic base off 16-byte alignment and slow every ds_read_b128 down)
-                unsigned* next_row = (unsigned*)(smem + lds_bytes_per_block(a.geom, sizeof(T), NW) - 16);
-                if (threadIdx.x == 0) *next_row = atomicAdd(a.queue, 1u);
-                __syncthreads();
-                r = uniform(*next_row);
-                __syncthreads();
-            } else {
+    if constexpr (EV::PIPELINED) {
+        // Software pipeline over the rows of this wave.  A row costs three dependent round trips to memory -- its
+        // descriptor, its indices, the factor rows those name -- and the solver in between leaves the memory pipe idle.
+        // Tickets (and descriptors) are fetched two rows ahead and the indices one row ahead, so that a row's gather
+        // starts the moment the previous row is stored.
+        unsigned r = blockIdx.x;
+        auto ticket = [&]() -> unsigned {
+            if (a.queue != nullptr) {
                 unsigned t = 0;
                 if (ev.lane == 0) t = atomicAdd(a.queue, 1u);
-                r = uniform(t);
+                return uniform(t);
             }
+            const unsigned t = r;
+            r += gridDim.x;
+            return t;
+        };
+        auto fetch = [&](unsigned t) -> RowDesc { return desc[t < a.nrows ? t : 0u]; };
+        unsigned t0 = ticket(), t1 = ticket();
+        RowDesc d0 = fetch(t0), d1 = fetch(t1);
+        if (t0 < a.nrows) ev.fetch_meta(a.indices + (((unsigned long long)d0.p0_hi << 32) | d0.p0_lo), d0.nnz);
+        while (t0 < a.nrows) {
+            const unsigned long long p0 = ((unsigned long long)d0.p0_hi << 32) | d0.p0_lo;
+            if (d0.nnz != 0) ev.gather(a.values + p0, d0.nnz);                  // indices are here: request the tile
+            const unsigned t2 = ticket();
+            const RowDesc d2 = fetch(t2);
+            if (t1 < a.nrows) ev.fetch_meta(a.indices + (((unsigned long long)d1.p0_hi << 32) | d1.p0_lo), d1.nnz);
+            solve_row<EV, T, NC, METHOD>(a, ev, bs, d0.lrow, d0.nnz);
+            t0 = t1; d0 = d1;
+            t1 = t2; d1 = d2;
         }
-        if (r >= a.nrows) break;
-        const unsigned this_r = r;
-        r += gridDim.x;
-        const unsigned lrow = uniform(a.perm[a.perm_begin + this_r]);
-        const unsigned long long p0 = a.indptr[lrow], p1 = a.indptr[lrow + 1];
-        const unsigned nnz = uniform((unsigned)(p1 - p0));
-        T* out = a.M + (size_t)(a.row_offset + lrow) * (size_t)k;
-        T* out_p = a.Mp != nullptr ? a.Mp + (size_t)(a.row_offset + lrow) * (size_t)a.ldM : nullptr;
-        T x[NC];
-        if (nnz == 0) {  // rows without data are forced to zero every half (quirk Q7)
-            PMF_EW x[i] = (T)0;
-            ev.store_vec(out, x);
-            if (out_p != nullptr) ev.store_vec(out_p, x);
-            continue;
-        }
-        ev.begin_row(a.indices + p0, a.values + p0, nnz);
-        ev.load_vec(out, x);
-
-        // per-row constant term: the k-vector itself, or (w != 1) the reference's Bsum_w row
-        //   (w - 1) sum_j F_j + Bsum          ref: src/poismf.c:85-123 (adjustment_Bsum)
-        T shift[NC];
-        PMF_EW shift[i] = bs[i];
-        const bool weighted = a.P.w != (T)1;
-        if (weighted) {
-            T cs[NC];
-            PMF_EW cs[i] = (T)0;
-            ev.tile_colsum(cs);
-            const T wm1 = a.P.w - (T)1.;
-            PMF_EW {
-                shift[i] = cs[i] * wm1;
-                shift[i] = shift[i] + bs[i];
+        return;
+    } else {
+        unsigned r = blockIdx.x;
+        for (;;) {
+            if (a.queue != nullptr) {
+                if constexpr (NW > 1) {
+                    // broadcast through the last 16 bytes of the DYNAMIC LDS block (a static __shared__ object
+                    // would shift the dynamic base off 16-byte alignment and slow every ds_read_b128 down)
+                    unsigned* next_row = (unsigned*)(smem + lds_bytes_per_block(a.geom, sizeof(T), NW) - 16);
+                    if (threadIdx.x == 0) *next_row = atomicAdd(a.queue, 1u);
+                    __syncthreads();
+                    r = uniform(*next_row);
+                    __syncthreads();
+                } else {
+                    unsigned t = 0;
+                    if (ev.lane == 0) t = atomicAdd(a.queue, 1u);
+                    r = uniform(t);
+                }
             }
-            if (METHOD == K_PG) { PMF_EW shift[i] = shift[i] * a.P.neg_step; }  // dscal_large, ref: :526, :576
+            if (r >= a.nrows) break;
+            const RowDesc d = desc[r];
+            r += gridDim.x;
+            const unsigned nnz = uniform(d.nnz);
+            const unsigned long long p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
+            if (nnz != 0) ev.begin_row(a.indices + p0, a.values + p0, nnz);
+            solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d.lrow), nnz);
         }
-
-        if constexpr (METHOD == K_PG) {
-            pg_row(ev, a.P, x, shift);
-        } else if constexpr (METHOD == K_CG) {
-            if (a.P.limit_step && ev.pq_cap > 0 && nnz <= (unsigned)ev.pq_cap) cg_row_cached(ev, a.P, shift, x, weighted);  // streamed rows only, see plan_geom
-            else cg_row(ev, a.P, shift, x, weighted);
-        } else {
-            T prev[NC];
-            PMF_EW prev[i] = x[i];
-            if (!a.reuse_prev) { PMF_EW x[i] = (T)1e-3; }                   // ref: src/poismf.c:379-381
-            (void)Tnc<T, NC, EV>::minimize(ev, a.P, shift, x);
-            if (a.early_stop) {                                             // ref: src/poismf.c:393-396
-                PMF_EW prev[i] = prev[i] - x[i];
-                const T moved = ev.dot(prev, prev);
-                if ((double)moved <= 1e-4 && ev.lane == 0 && ev.wid == 0) atomicAdd(a.n_unchanged, 1u);
-            }
-        }
-        ev.store_vec(out, x);
-        if (out_p != nullptr) ev.store_vec(out_p, x);
     }
 }
 
@@ -162,7 +208,13 @@ template <class T, int METHOD, int S, int G, int NS>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REG_WAVES(4 * S * NS)))) void half_sweep_reg_kernel(const HalfArgs<T> a)
 {
     RegEval<T, S, G, NS> ev;
+#ifdef PMF_TIMING
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
     sweep_rows<RegEval<T, S, G, NS>, T, RegEval<T, S, G, NS>::NC, METHOD, 1>(a, ev, nullptr);
+#ifdef PMF_TIMING
+    if (ev.lane == 0) atomicAdd(&g_pmf_timing[5], __builtin_amdgcn_s_memtime() - t_kernel);
+#endif
 }
 
 // ---- compact factor -> line-padded copy (the pad columns stay zero from the allocation) --------------------------
@@ -270,6 +322,7 @@ struct Half {
     unsigned* d_indices = nullptr;
     real_t* d_values = nullptr;
     unsigned* d_perm = nullptr;
+    RowDesc* d_desc = nullptr;
     std::vector<Bin> bins;
 };
 
@@ -308,6 +361,7 @@ void free_half(Half& h)
     if (h.d_indices) (void)hipFree(h.d_indices);
     if (h.d_values) (void)hipFree(h.d_values);
     if (h.d_perm) (void)hipFree(h.d_perm);
+    if (h.d_desc) (void)hipFree(h.d_desc);
     h = Half();
 }
 
@@ -356,6 +410,13 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     HIP_TRY(hipMemcpyAsync(h.d_indices, lidx.data(), sizeof(unsigned) * h.nnz, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(h.d_values, val + base, sizeof(real_t) * h.nnz, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(h.d_perm, perm.data(), sizeof(unsigned) * nloc, hipMemcpyHostToDevice, stream));
+    std::vector<RowDesc> desc(nloc ? nloc : 1);
+    for (size_t i = 0; i < nloc; i++) {
+        const unsigned long long p0 = lptr[perm[i]];
+        desc[i] = { (unsigned)p0, (unsigned)(p0 >> 32), (unsigned)(lptr[perm[i] + 1] - p0), perm[i] };
+    }
+    HIP_TRY(hipMalloc(&h.d_desc, sizeof(RowDesc) * (nloc ? nloc : 1)));
+    HIP_TRY(hipMemcpyAsync(h.d_desc, desc.data(), sizeof(RowDesc) * nloc, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));  // host staging vectors die here
     return 0;
 }
@@ -556,9 +617,13 @@ int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream
         // A gathered row of B bytes at an arbitrary 8-byte offset touches (B + 120) / 128 lines of 128 bytes on average;
         // in a copy whose rows start on line boundaries it touches ceil(B / 128).  k = 50 fp32: 2.5 -> 2 lines.
         const size_t rowb = k * sizeof(real_t);
-        const size_t padb = (rowb + 127) / 128 * 128;
+        size_t padb = (rowb + 127) / 128 * 128;
         static const bool no_pad = getenv("POISMF_HIP_NO_PAD") != nullptr;  // testing knob
-        if (!no_pad && padb != rowb && (double)padb <= 0.9 * (double)(rowb + 120)) {
+        const bool line_pad = !no_pad && padb != rowb && (double)padb <= 0.9 * (double)(rowb + 120);
+        // and a row that does not end on a 16-byte slot boundary is padded to one in any case: the gathers fetch whole
+        // slots and rely on the excess of the last one being zero
+        if (!line_pad) padb = (rowb + 15) / 16 * 16;
+        if (padb != rowb) {
             s->ld = padb / sizeof(real_t);
             const size_t pslack = padb + 16;
             if (hipMalloc(&s->dAp, dimA * padb + pslack) != hipSuccess) return fail();
@@ -719,7 +784,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     HalfArgs<real_t> a;
     a.M = M; a.F = Fg;
     a.Mp = Mp; a.ldM = (int)s->ld;
-    a.indptr = h.d_indptr; a.indices = h.d_indices; a.values = h.d_values; a.perm = h.d_perm;
+    a.indptr = h.d_indptr; a.indices = h.d_indices; a.values = h.d_values; a.perm = h.d_perm; a.desc = h.d_desc;
     a.row_offset = (unsigned)h.row_begin;
     a.bsum = s->d_bsum;
     a.P.l2 = p->l2_reg; a.P.w = p->w_mult;

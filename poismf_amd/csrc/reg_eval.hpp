@@ -100,11 +100,13 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     static constexpr int NC = NS * SN;            // elements per lane
     static constexpr int NB = (S + G - 1) / G;    // batches of G steps = 64 nonzeros
     static constexpr int NW = 1;
+    static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
     static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
 
     SA t[S][NS];    // the tile
     T a[NC];        // current point (this lane's slots)
     T xr[NB];       // x_j of the nonzero whose pred this lane finishes in batch b: j = 64 b + JG g + jg
+    unsigned idx_n[NB];  // column indices of the row whose tile is requested next, same layout (fetch_meta -> gather)
     // launch constants
     const T* F;
     unsigned zero_row;
@@ -164,46 +166,76 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
         return rsum(s);
     }
     __device__ __forceinline__ T nrm2(const T (&u)[NC]) const { return (T)d_sqrt((double)dot(u, u)); }
+    // k-vector in global memory <-> registers, one 16-byte access per slot (the vectors this engine touches -- factor
+    // rows, the column-sum vector -- all have >= 16 bytes of slack behind them, so the last, partly filled slot may be
+    // read whole; it is written element by element)
     __device__ __forceinline__ void load_vec(const T* p, T (&x)[NC]) const
     {
 #pragma unroll
-        for (int i = 0; i < NC; i++) x[i] = act[i] ? p[elem[i]] : (T)0;
+        for (int n = 0; n < NS; n++) {
+            SU v;
+#pragma unroll
+            for (int e = 0; e < SN; e++) v.v[e] = (T)0;
+            if (slot_on[n]) v = *(const SU*)(p + (g + G * n) * SN);
+#pragma unroll
+            for (int e = 0; e < SN; e++) x[n * SN + e] = act[n * SN + e] ? v.v[e] : (T)0;
+        }
     }
     __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
     {
         if (jg == 0) {
 #pragma unroll
-            for (int i = 0; i < NC; i++)
-                if (act[i]) p[elem[i]] = x[i];
+            for (int n = 0; n < NS; n++) {
+                if (act[n * SN + SN - 1]) {          // whole slot inside the row
+                    SU v;
+#pragma unroll
+                    for (int e = 0; e < SN; e++) v.v[e] = x[n * SN + e];
+                    *(SU*)(p + (g + G * n) * SN) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < SN; e++)
+                        if (act[n * SN + e]) p[elem[n * SN + e]] = x[n * SN + e];
+                }
+            }
         }
     }
 
     // ---- gather: indices / values coalesced in the "finishing lane" layout, then NS 16-byte loads per step ----
     // All loads of a row are issued back to back, unconditionally: steps past the end of the row and lanes whose
-    // slot does not exist fetch from row `zero_row` = dimF, an all-zero row the session keeps behind the factor, so
-    // nothing needs masking afterwards except the excess of the last slot.
+    // slot does not exist fetch from row `zero_row` = dimF, an all-zero row the session keeps behind the factor, and
+    // the gathered copy of the factor has rows of whole 16-byte slots ending in zeros (the session pads it when
+    // k * sizeof(T) is not a multiple of 16), so nothing needs masking afterwards.
+    // Split in two so that sweep_rows can run fetch_meta for the NEXT row while the solver works on the current one.
+    __device__ __forceinline__ void fetch_meta(const unsigned* ind, unsigned nnz_next)
+    {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const unsigned j = (unsigned)(64 * b + jlane);
+            idx_n[b] = j < nnz_next ? ind[j] : zero_row;   // steps past the end of the row fetch the all-zero row behind F
+        }
+    }
     __device__ __forceinline__ void begin_row(const unsigned* ind, const T* val, unsigned nnz_)
+    {
+        fetch_meta(ind, nnz_);
+        gather(val, nnz_);
+    }
+    __device__ __forceinline__ void gather(const T* val, unsigned nnz_)
     {
         nnz = nnz_;
         unsigned idx[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             const unsigned j = (unsigned)(64 * b + jlane);
-            const bool ok = j < nnz;
-            idx[b] = ok ? ind[j] : zero_row;   // steps past the end of the row fetch the all-zero row behind F
-            xr[b] = ok ? val[j] : (T)0;
+            idx[b] = idx_n[b];
+            xr[b] = j < nnz ? val[j] : (T)0;
         }
         // byte offset of this lane's slot of factor row c: 24-bit multiply-add, 32-bit result (the host only takes
         // this engine when the factor has < 2^24 rows and < 4 GiB).  Lanes whose slot does not exist read the first
         // 16 bytes of the zero row instead.
         const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
         unsigned lane_off[NS];
-        bool cut[NS];
 #pragma unroll
-        for (int n = 0; n < NS; n++) {
-            lane_off[n] = slot_on[n] ? (unsigned)((g + G * n) * 16) : 0u;
-            cut[n] = slot_last[n] && tail < SN;  // the last slot of a factor row reads past its end: zero the excess
-        }
+        for (int n = 0; n < NS; n++) lane_off[n] = slot_on[n] ? (unsigned)((g + G * n) * 16) : 0u;
         static_for<0, S>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // index of nonzero JG s + jg sits in lane s % G of group jg
@@ -212,13 +244,11 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
             for (int n = 0; n < NS; n++) {
                 const unsigned off = __umul24(slot_on[n] ? c : zero_row, rowbytes) + lane_off[n];
                 const SU v = *(const SU*)((const char*)F + (size_t)off);
-                t[s][n].v[0] = v.v[0];
 #pragma unroll
-                for (int e = 1; e < SN; e++) t[s][n].v[e] = (cut[n] && e >= tail) ? (T)0 : v.v[e];
+                for (int e = 0; e < SN; e++) t[s][n].v[e] = v.v[e];
             }
         });
     }
-
     __device__ __forceinline__ void set_point(const T (&x)[NC])
     {
 #pragma unroll

@@ -97,6 +97,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
     static constexpr int NS = NC / SN;
+    static constexpr bool PIPELINED = false;  // sweep_rows: no cross-row prefetch (the LDS tile has one set of index buffers)
     static_assert(NC % SN == 0, "a lane holds whole 16-byte slots");
 
     // LDS carve-out of this wave

@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from poismf_amd import api, build, harness, synth
 here = os.path.dirname(os.path.abspath(__file__))
-build.lib_path = lambda use_float: os.path.join(here, "libpoismf_hip_f_timing.so")
+if os.path.exists(os.path.join(here, "libpoismf_hip_f_timing.so")):
+    build.lib_path = lambda use_float: os.path.join(here, "libpoismf_hip_f_timing.so")
+# otherwise: the in-tree library, built with POISMF_HIP_EXTRA_FLAGS=-DPMF_TIMING python -m poismf_amd.build --force
 maxupd = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 method = sys.argv[2] if len(sys.argv) > 2 else "pg"
 coo = synth.uniform_coo(10 ** 5, 10 ** 5, 10 ** 7, seed=1)
@@ -30,6 +32,8 @@ for _ in range(n):
 lib.poismf_hip_debug_timing(buf)
 t = np.array(list(buf)[:6], dtype=np.float64)
 names = ["gather", "phase1", "coef/div", "phase2", "combine", "kernel(total wave-cycles)"]
+if os.environ.get("PMF_ROW_TIMERS"):   # register engine: row-level timers of sweep_rows
+    names = ["row hand-out", "gather (tile landed)", "solver", "store", "-", "kernel(total wave-cycles)"]
 km = sum(s.kernel_time(w)[0] for w in (0, 1)) / n
 print(f"method={method} maxupd={maxupd}: kernel {km:.3f} ms per sweep")
 for nm, v in zip(names, t):
