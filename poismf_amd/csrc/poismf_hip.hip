@@ -198,14 +198,19 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
 #endif
 }
 
-// waves per SIMD the register allocator is asked to make room for, by tile registers TR = 4 S NS (512 VGPRs per
-// SIMD lane; the solvers' working set comes on top)
-#ifndef REG_WAVES
-#define REG_WAVES(TR) ((TR) <= 16 ? 6 : (TR) <= 32 ? 5 : (TR) <= 64 ? 4 : (TR) <= 112 ? 3 : 2)
-#endif
+// Waves per SIMD the register allocator is asked to make room for: the largest count whose VGPR budget (512 per SIMD
+// lane, granules of 8) holds the tile (TR = 4 S NS registers) plus the solver's working set (PG ~56, CG ~120, TNCG ~150;
+// a few dozen bytes of the idle TNC vectors may spill around the evaluations).
+constexpr int reg_waves(int tile_regs, int method)
+{
+    const int need = tile_regs + (method == K_PG ? 56 : method == K_CG ? 120 : 150);
+    for (int w : { 8, 6, 5, 4, 3, 2 })
+        if ((512 / w) / 8 * 8 >= need) return w;
+    return 1;
+}
 // Register-tile engine (reg_eval.hpp) for rows of at most (64 / G) S nonzeros: no LDS at all, waves per CU set by VGPRs.
 template <class T, int METHOD, int S, int G, int NS>
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(REG_WAVES(4 * S * NS)))) void half_sweep_reg_kernel(const HalfArgs<T> a)
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(reg_waves(4 * S * NS, METHOD)))) void half_sweep_reg_kernel(const HalfArgs<T> a)
 {
     RegEval<T, S, G, NS> ev;
 #ifdef PMF_TIMING
@@ -517,11 +522,26 @@ template <int METHOD, int S, int NS> int launch_reg(hipStream_t stream, const Ha
     return 0;
 }
 
+// longest row (nonzeros) each solver runs from a register tile; beyond it the LDS engine has more waves per CU
+#ifndef PMF_REG_MAX_CG
+#define PMF_REG_MAX_CG 128
+#endif
+#ifndef PMF_REG_MAX_TNCG
+#define PMF_REG_MAX_TNCG 96
+#endif
+constexpr int REG_NNZ_MAX_CG = PMF_REG_MAX_CG, REG_NNZ_MAX_TNCG = PMF_REG_MAX_TNCG;
+unsigned reg_nnz_max(int method) { return method == POISMF_PG ? REG_NNZ_MAX : method == POISMF_CG ? REG_NNZ_MAX_CG : REG_NNZ_MAX_TNCG; }
+
 template <int S, int NS> int launch_reg_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     switch (method) {
         case POISMF_PG: return launch_reg<K_PG, S, NS>(stream, a, grid_mult);
-        default: return 1;
+        case POISMF_CG:
+            if constexpr (S * REG_JG <= REG_NNZ_MAX_CG) return launch_reg<K_CG, S, NS>(stream, a, grid_mult);
+            else return 1;
+        default:
+            if constexpr (S * REG_JG <= REG_NNZ_MAX_TNCG) return launch_reg<K_TNCG, S, NS>(stream, a, grid_mult);
+            else return 1;
     }
 }
 
@@ -534,7 +554,6 @@ template <int NS> int launch_reg_steps(hipStream_t stream, int S, int method, co
     }
     return 1;
 }
-bool reg_engine_supports(int method) { return method == POISMF_PG; }
 
 // Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
 constexpr unsigned LONG_ROW_NNZ = 8192;
@@ -813,7 +832,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     std::vector<Launch> launches;
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots, and 24-bit row ids / 32-bit byte offsets into the factor
-    const bool reg_ok = !no_reg && reg_engine_supports(p->method) && (s->k * sizeof(real_t) + 15) / 16 <= 16 &&
+    const bool reg_ok = !no_reg && (s->k * sizeof(real_t) + 15) / 16 <= 16 &&
                         dimF < ((size_t)1 << 24) && (dimF + 1) * ldF * sizeof(real_t) + 16 < ((size_t)1 << 32);
     static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
@@ -821,7 +840,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     for (const Bin& b : h.bins) {
         TileGeom g = plan_geom(s->k, b.max_nnz, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) g.resident = 0;  // one pass: "gather once" and "stream" are the same thing
-        if (reg_ok && b.max_nnz <= (unsigned)REG_NNZ_MAX) {
+        if (reg_ok && b.max_nnz <= reg_nnz_max(p->method)) {
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
             // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
             const int S = reg_steps_for(b.max_nnz);
