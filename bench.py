@@ -237,9 +237,14 @@ def main():
                                                               "RCCL all-gather of the updated shard after each half"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "half_sweep_kernel", "kernel_ms_per_sweep": k_ms_sweep,
+                         "kernel": "half_sweep_reg_kernel<float, pg, S> (register-tile row kernel; one launch per row-length bin, "
+                                   "S = 24/28/32/40 tile steps on this workload)",
+                         "kernel_ms_per_sweep": k_ms_sweep,
                          "algorithmic_bytes_per_sweep": int(sum(b_half)), "half_sweeps_timed": int(launches),
-                         "note": "one half-sweep = one launch per row bin; bytes = nnz*(4+s+k*s) + 2*dimM*k*s + (dimM+1)*8 per half"},
+                         "note": "achieved = algorithmic bytes of one sweep's row-kernel launches / their summed duration (HIP events on "
+                                 "the session stream around each half's launches; serial launches, so this equals sum(Calls x AverageNs) "
+                                 "of the half_sweep_* rows of profiles/r01/kt_pg10_kernel_stats.csv); bytes = nnz*(4+s+k*s) + 2*dimM*k*s + "
+                                 "(dimM+1)*8 per half; traffic = fabric-side bytes per sweep from the PMC passes in profiles/r01/"},
             "results_finite": res["finite"],
         }
         if world == 1 and not a.no_extra:

@@ -158,7 +158,7 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
                 if constexpr (NW > 1) {
                     // broadcast through the last 16 bytes of the DYNAMIC LDS block (a static __shared__ object
                     // would shift the dynamic base off 16-byte alignment and slow every ds_read_b128 down)
-                    unsigned* next_row = (unsigned*)(smem + lds_bytes_per_block(a.geom, sizeof(T), NW) - 16);
+                    unsigned* next_row = ev.ticket_slot();
                     if (threadIdx.x == 0) *next_row = atomicAdd(a.queue, 1u);
                     __syncthreads();
                     r = uniform(*next_row);
@@ -220,6 +220,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(reg_waves(
 #ifdef PMF_TIMING
     if (ev.lane == 0) atomicAdd(&g_pmf_timing[5], __builtin_amdgcn_s_memtime() - t_kernel);
 #endif
+}
+
+// The same engine with REG_NW wavefronts per row (reg_eval.hpp, NW_ > 1): rows of up to REG_NW (64 / G) S nonzeros.
+// Two waves per SIMD = one workgroup per CU (two when the tile is small).
+constexpr int REG_NW = 8;
+template <class T, int METHOD, int S, int G, int NS>
+__global__ __launch_bounds__(WAVE* REG_NW) __attribute__((amdgpu_waves_per_eu(2, 4))) void half_sweep_regw_kernel(const HalfArgs<T> a)
+{
+    using EV = RegEval<T, S, G, NS, REG_NW>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
+    EV ev;
+    sweep_rows<EV, T, EV::NC, METHOD, REG_NW>(a, ev, smem);
 }
 
 // ---- compact factor -> line-padded copy (the pad columns stay zero from the allocation) --------------------------
@@ -524,10 +536,10 @@ template <int METHOD, int S, int NS> int launch_reg(hipStream_t stream, const Ha
 
 // longest row (nonzeros) each solver runs from a register tile; beyond it the LDS engine has more waves per CU
 #ifndef PMF_REG_MAX_CG
-#define PMF_REG_MAX_CG 128
+#define PMF_REG_MAX_CG 160
 #endif
 #ifndef PMF_REG_MAX_TNCG
-#define PMF_REG_MAX_TNCG 96
+#define PMF_REG_MAX_TNCG 160
 #endif
 constexpr int REG_NNZ_MAX_CG = PMF_REG_MAX_CG, REG_NNZ_MAX_TNCG = PMF_REG_MAX_TNCG;
 unsigned reg_nnz_max(int method) { return method == POISMF_PG ? REG_NNZ_MAX : method == POISMF_CG ? REG_NNZ_MAX_CG : REG_NNZ_MAX_TNCG; }
@@ -543,6 +555,58 @@ template <int S, int NS> int launch_reg_method(hipStream_t stream, int method, c
             if constexpr (S * REG_JG <= REG_NNZ_MAX_TNCG) return launch_reg<K_TNCG, S, NS>(stream, a, grid_mult);
             else return 1;
     }
+}
+
+// REG_NW waves per row: the longest share of a row one wave keeps in registers, per solver (CG / TNCG carry more state)
+constexpr int REGW_WAVE_NNZ_MAX_PG = 160, REGW_WAVE_NNZ_MAX_CG = 128, REGW_WAVE_NNZ_MAX_TNCG = 96;
+unsigned regw_nnz_max(int method)
+{
+    return (unsigned)REG_NW * (method == POISMF_PG ? REGW_WAVE_NNZ_MAX_PG : method == POISMF_CG ? REGW_WAVE_NNZ_MAX_CG : REGW_WAVE_NNZ_MAX_TNCG);
+}
+// tile steps for a row of max_nnz nonzeros split over REG_NW waves (each wave's share is rounded up to whole steps)
+int regw_steps_for(unsigned max_nnz)
+{
+    const unsigned share = ((max_nnz + REG_NW - 1) / REG_NW + REG_JG - 1) / REG_JG * REG_JG;
+    return reg_steps_for(std::max(32u, share));
+}
+
+template <int METHOD, int S, int NS> int launch_regw(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    auto kern = half_sweep_regw_kernel<real_t, METHOD, S, REG_G, NS>;
+    static int occ = 0;  // workgroups per CU
+    if (occ == 0) {
+        int n = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), WAVE * REG_NW, 0));
+        occ = std::max(1, n);
+    }
+    const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)NUM_CU * (size_t)occ * grid_mult);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * REG_NW), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int S, int NS> int launch_regw_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    if constexpr (S * REG_JG < 32) return 1;
+    else switch (method) {
+        case POISMF_PG: return launch_regw<K_PG, S, NS>(stream, a, grid_mult);
+        case POISMF_CG:
+            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_CG) return launch_regw<K_CG, S, NS>(stream, a, grid_mult);
+            else return 1;
+        default:
+            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG) return launch_regw<K_TNCG, S, NS>(stream, a, grid_mult);
+            else return 1;
+    }
+}
+
+template <int NS> int launch_regw_steps(hipStream_t stream, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    switch (S) {
+#define X(NZ) case (NZ) / REG_JG: return launch_regw_method<(NZ) / REG_JG, NS>(stream, method, a, grid_mult);
+        PMF_REG_SIZES(X)
+#undef X
+    }
+    return 1;
 }
 
 template <int NS> int launch_reg_steps(hipStream_t stream, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
@@ -844,11 +908,21 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
             // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
             const int S = reg_steps_for(b.max_nnz);
-            if (!launches.empty() && launches.back().reg_S >= S && (launches.back().reg_S == S || b.count < 4096u) &&
-                launches.back().begin + launches.back().count == b.begin)
+            if (!launches.empty() && launches.back().nw == 1 && launches.back().reg_S >= S &&
+                (launches.back().reg_S == S || b.count < 4096u) && launches.back().begin + launches.back().count == b.begin)
                 launches.back().count += b.count;
             else
                 launches.push_back({ b.begin, b.count, g, 1, S });
+            continue;
+        }
+        if (reg_ok && b.max_nnz <= regw_nnz_max(p->method)) {
+            // medium rows: REG_NW waves share a row, each keeps its part of the tile in registers
+            const int S = regw_steps_for(b.max_nnz);
+            if (!launches.empty() && launches.back().nw == REG_NW && launches.back().reg_S >= S &&
+                (launches.back().reg_S == S || b.count < 2048u) && launches.back().begin + launches.back().count == b.begin)
+                launches.back().count += b.count;
+            else
+                launches.push_back({ b.begin, b.count, g, REG_NW, S });
             continue;
         }
         if (!no_long && b.max_nnz > long_thr) {
@@ -886,7 +960,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const bool no_fork = getenv("POISMF_HIP_NO_FORK") != nullptr;  // testing knob
     static const bool fork_bins = getenv("POISMF_HIP_FORK_BINS") != nullptr;  // tuning knob
     bool any_long = false;
-    for (const Launch& L : launches) any_long = any_long || L.nw > 1;
+    for (const Launch& L : launches) any_long = any_long || (L.nw > 1 && L.reg_S == 0);
     const bool forked = !no_fork && launches.size() > 1 && (any_long || fork_bins);
     hipStream_t long_stream = forked ? s->aux_stream : s->stream;
     double queued[2] = { 0.0, 0.0 };
@@ -914,6 +988,11 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         if (L.reg_S > 0) {
             int rrc;
+            if (L.nw > 1) {
+                if constexpr (REG_G == 16) rrc = launch_regw_steps<1>(s->stream, L.reg_S, p->method, a, grid_mult);
+                else rrc = a.geom.s_load <= REG_G ? launch_regw_steps<1>(s->stream, L.reg_S, p->method, a, grid_mult)
+                                                  : launch_regw_steps<2>(s->stream, L.reg_S, p->method, a, grid_mult);
+            } else
             if constexpr (REG_G == 16) rrc = launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult);
             else rrc = a.geom.s_load <= REG_G ? launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult)
                                               : launch_reg_steps<2>(bin_stream, L.reg_S, p->method, a, grid_mult);

@@ -91,7 +91,12 @@ __device__ __forceinline__ float coef_div(float num, float den)
 }
 __device__ __forceinline__ double coef_div(double num, double den) { return num / den; }
 
-template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
+// NW_ > 1: a workgroup of NW_ wavefronts shares ONE row, for rows longer than one wave's registers hold (k = 50 fp32,
+// NW_ = 8: up to 1280 nonzeros stay on chip).  Wave w keeps nonzeros [w C, (w + 1) C) of the row in its tile, C =
+// ceil(nnz / NW_) rounded up to a whole step; every wave keeps its own copy of the solver state and runs the same
+// wave-uniform control flow; the NW_ partial gradients / log-likelihood sums of an evaluation are added through LDS in
+// wave order behind a workgroup barrier, so all copies stay bit-identical (the scheme of RowEval's long-row path).
+template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
@@ -99,8 +104,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     static constexpr int JG = WAVE / G;           // nonzeros per step
     static constexpr int NC = NS * SN;            // elements per lane
     static constexpr int NB = (S + G - 1) / G;    // batches of G steps = 64 nonzeros
-    static constexpr int NW = 1;
-    static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
+    static constexpr int NW = NW_;
+    static constexpr bool PIPELINED = NW_ == 1;   // sweep_rows prefetches the next row's indices during the solver
+    static constexpr int KP = 16 * SN;            // elements of a (padded) k-vector in the cross-wave scratch
+    static constexpr int SMEM_BYTES = NW_ > 1 ? NW_ * KP * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) + 16 : 0;
     static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
 
     SA t[S][NS];    // the tile
@@ -117,18 +124,24 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     int elem[NC];
     bool act[NC];
     bool slot_on[NS], slot_last[NS];
-    unsigned nnz;
+    unsigned nnz;   // nonzeros of the row held by THIS wave
+    T* red_part;    // NW > 1: [NW][KP] partial gradients, shared by the workgroup
+    double* red_l;  // NW > 1: [NW] partial log-likelihood sums
+    unsigned* ticket_word;
     // interface parity with RowEval (the cached line search is for streamed rows only)
     int pq_cap;
     T* pbuf;
     T* qbuf;
 
-    __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char*)
+    __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
         lane = lane_id();
+        red_part = (T*)smem;
+        red_l = (double*)(smem + NW * KP * sizeof(T));
+        ticket_word = (unsigned*)(smem + NW * KP * sizeof(T) + 16 * ((NW * 8 + 15) / 16));
         F = F_;
         k = geo.k; ldF = geo.ldF; s_load = geo.s_load; zero_row = geo.zero_row;
-        g = lane & (G - 1); jg = lane / G; wid = 0;
+        g = lane & (G - 1); jg = lane / G; wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
         jlane = JG * g + jg;
         cls8 = (lane & 8) != 0; cls4 = (lane & 4) != 0; cls2 = (lane & 2) != 0; cls1 = (lane & 1) != 0;
         tail = k - (s_load - 1) * SN;
@@ -183,7 +196,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     }
     __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
     {
-        if (jg == 0) {
+        if (jg == 0 && wid == 0) {
 #pragma unroll
             for (int n = 0; n < NS; n++) {
                 if (act[n * SN + SN - 1]) {          // whole slot inside the row
@@ -216,8 +229,40 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
     }
     __device__ __forceinline__ void begin_row(const unsigned* ind, const T* val, unsigned nnz_)
     {
-        fetch_meta(ind, nnz_);
-        gather(val, nnz_);
+        if constexpr (NW > 1) {   // this wave's share of the row
+            const unsigned C = ((nnz_ + NW - 1) / NW + JG - 1) / JG * JG;
+            const unsigned c0 = (unsigned)wid * C;
+            const unsigned mine = c0 < nnz_ ? (nnz_ - c0 < C ? nnz_ - c0 : C) : 0u;
+            fetch_meta(ind + c0, mine);
+            gather(val + c0, mine);
+        } else {
+            fetch_meta(ind, nnz_);
+            gather(val, nnz_);
+        }
+    }
+    __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
+
+    // NW > 1: add up the NW waves' partial results (fixed order; every wave ends with the same bits)
+    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum) const
+    {
+        if constexpr (NW > 1) {
+            if (jg == 0) {
+#pragma unroll
+                for (int i = 0; i < NC; i++)
+                    if (act[i]) red_part[wid * KP + elem[i]] = tot[i];
+            }
+            if (lane == 0) red_l[wid] = lsum;
+            __syncthreads();
+            lsum = 0.0;
+#pragma unroll
+            for (int i = 0; i < NC; i++) tot[i] = (T)0;
+            for (int w = 0; w < NW; w++) {
+                lsum += red_l[w];
+#pragma unroll
+                for (int i = 0; i < NC; i++) tot[i] += act[i] ? red_part[w * KP + elem[i]] : (T)0;
+            }
+            __syncthreads();  // the scratch is free again before anybody starts the next evaluation
+        }
     }
     __device__ __forceinline__ void gather(const T* val, unsigned nnz_)
     {
@@ -342,9 +387,24 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
                 });
             }
         });
-        if constexpr (WANT_G) combine_groups(part, acc);
-        if constexpr (WANT_F) return wave_sum(lpart);
-        else return 0.0;
+        if constexpr (NW > 1) {
+            T tot[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) tot[i] = (T)0;
+            if constexpr (WANT_G) combine_groups(part, tot);
+            double lsum = 0.0;
+            if constexpr (WANT_F) lsum = wave_sum(lpart);
+            combine_waves(tot, lsum);
+            if constexpr (WANT_G) {
+#pragma unroll
+                for (int i = 0; i < NC; i++) acc[i] += tot[i];
+            }
+            return lsum;
+        } else {
+            if constexpr (WANT_G) combine_groups(part, acc);
+            if constexpr (WANT_F) return wave_sum(lpart);
+            else return 0.0;
+        }
     }
 
     __device__ __forceinline__ double logsum_cached(T) const { return 0.0; }
@@ -364,7 +424,18 @@ template <class T, int S, int G_ = 16, int NS_ = 1> struct RegEval {
                 for (int e = 0; e < SN; e++) part[m * SN + e] += t[s][m].v[e];   // steps past the row's end hold zeros
             }
         }
-        combine_groups(part, acc);
+        if constexpr (NW > 1) {
+            T tot[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) tot[i] = (T)0;
+            combine_groups(part, tot);
+            double unused = 0.0;
+            combine_waves(tot, unused);
+#pragma unroll
+            for (int i = 0; i < NC; i++) acc[i] += tot[i];
+        } else {
+            combine_groups(part, acc);
+        }
     }
 };
 

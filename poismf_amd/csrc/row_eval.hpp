@@ -159,6 +159,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         coefb = (T*)p; p += 64 * sizeof(T);
         pq_cap = geo.pq_cap;
         pbuf = (T*)p; qbuf = pbuf + pq_cap;
+        ticket_word = (unsigned*)(smem + lds_bytes_per_block(geo, sizeof(T), NW) - 16);
         gj0 = lane / s_load; gt0 = lane % s_load;
         gdj = WAVE / s_load; gdt = WAVE % s_load;
 #pragma unroll
@@ -320,6 +321,8 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         }
     }
 
+    unsigned* ticket_word;  // NW > 1: one LDS word for the row-queue broadcast (last 16 bytes of the block)
+    __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
     __device__ __forceinline__ void begin_row(const unsigned* ind_, const T* val_, unsigned nnz_)
     {
         ind = ind_; val = val_; nnz = nnz_;

@@ -16,4 +16,4 @@ for r in csv.DictReader(open(path)):
 for name, cs in acc.items():
     print(name)
     for c, v in sorted(cs.items()):
-        print(f"   {c:32s} n={len(v):4d} mean={sum(v)/len(v):.6g}")
+        print(f"   {c:32s} n={len(v):4d} mean={sum(v)/len(v):.6g} sum={sum(v):.6g}")
