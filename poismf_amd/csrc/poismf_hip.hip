@@ -128,6 +128,14 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
         unsigned r = blockIdx.x;
         auto ticket = [&]() -> unsigned {
             if (a.queue != nullptr) {
+                if constexpr (NW > 1) {   // one atomic per workgroup, broadcast through LDS
+                    unsigned* slot = ev.ticket_slot();
+                    if (threadIdx.x == 0) *slot = atomicAdd(a.queue, 1u);
+                    __syncthreads();
+                    const unsigned t = uniform(*slot);
+                    __syncthreads();
+                    return t;
+                }
                 unsigned t = 0;
                 if (ev.lane == 0) t = atomicAdd(a.queue, 1u);
                 return uniform(t);

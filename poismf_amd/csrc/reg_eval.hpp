@@ -105,7 +105,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     static constexpr int NC = NS * SN;            // elements per lane
     static constexpr int NB = (S + G - 1) / G;    // batches of G steps = 64 nonzeros
     static constexpr int NW = NW_;
-    static constexpr bool PIPELINED = NW_ == 1;   // sweep_rows prefetches the next row's indices during the solver
+    static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
     static constexpr int KP = 16 * SN;            // elements of a (padded) k-vector in the cross-wave scratch
     static constexpr int SMEM_BYTES = NW_ > 1 ? NW_ * KP * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) + 16 : 0;
     static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
@@ -219,26 +219,32 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     // the gathered copy of the factor has rows of whole 16-byte slots ending in zeros (the session pads it when
     // k * sizeof(T) is not a multiple of 16), so nothing needs masking afterwards.
     // Split in two so that sweep_rows can run fetch_meta for the NEXT row while the solver works on the current one.
-    __device__ __forceinline__ void fetch_meta(const unsigned* ind, unsigned nnz_next)
+    // this wave's share [c0, c0 + mine) of a row of nnz_row nonzeros (NW = 1: the whole row)
+    __device__ __forceinline__ void my_share(unsigned nnz_row, unsigned& c0, unsigned& mine) const
     {
+        if constexpr (NW > 1) {
+            const unsigned C = ((nnz_row + NW - 1) / NW + JG - 1) / JG * JG;
+            c0 = (unsigned)wid * C;
+            mine = c0 < nnz_row ? (nnz_row - c0 < C ? nnz_row - c0 : C) : 0u;
+        } else {
+            c0 = 0u; mine = nnz_row;
+        }
+    }
+    // ind / val: the row's first nonzero; nnz_row: its length
+    __device__ __forceinline__ void fetch_meta(const unsigned* ind, unsigned nnz_row)
+    {
+        unsigned c0, mine;
+        my_share(nnz_row, c0, mine);
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             const unsigned j = (unsigned)(64 * b + jlane);
-            idx_n[b] = j < nnz_next ? ind[j] : zero_row;   // steps past the end of the row fetch the all-zero row behind F
+            idx_n[b] = j < mine ? ind[c0 + j] : zero_row;   // steps past the end of the row fetch the all-zero row behind F
         }
     }
-    __device__ __forceinline__ void begin_row(const unsigned* ind, const T* val, unsigned nnz_)
+    __device__ __forceinline__ void begin_row(const unsigned* ind, const T* val, unsigned nnz_row)
     {
-        if constexpr (NW > 1) {   // this wave's share of the row
-            const unsigned C = ((nnz_ + NW - 1) / NW + JG - 1) / JG * JG;
-            const unsigned c0 = (unsigned)wid * C;
-            const unsigned mine = c0 < nnz_ ? (nnz_ - c0 < C ? nnz_ - c0 : C) : 0u;
-            fetch_meta(ind + c0, mine);
-            gather(val + c0, mine);
-        } else {
-            fetch_meta(ind, nnz_);
-            gather(val, nnz_);
-        }
+        fetch_meta(ind, nnz_row);
+        gather(val, nnz_row);
     }
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
 
@@ -264,15 +270,16 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             __syncthreads();  // the scratch is free again before anybody starts the next evaluation
         }
     }
-    __device__ __forceinline__ void gather(const T* val, unsigned nnz_)
+    __device__ __forceinline__ void gather(const T* val, unsigned nnz_row)
     {
-        nnz = nnz_;
+        unsigned c0;
+        my_share(nnz_row, c0, nnz);
         unsigned idx[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             const unsigned j = (unsigned)(64 * b + jlane);
             idx[b] = idx_n[b];
-            xr[b] = j < nnz ? val[j] : (T)0;
+            xr[b] = j < nnz ? val[c0 + j] : (T)0;
         }
         // byte offset of this lane's slot of factor row c: 24-bit multiply-add, 32-bit result (the host only takes
         // this engine when the factor has < 2^24 rows and < 4 GiB).  Lanes whose slot does not exist read the first
