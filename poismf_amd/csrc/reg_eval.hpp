@@ -91,6 +91,57 @@ __device__ __forceinline__ float coef_div(float num, float den)
 }
 __device__ __forceinline__ double coef_div(double num, double den) { return num / den; }
 
+// The two upper levels of the butterfly on floats, all folds of a level in one block: the class of a lane is a set of
+// DPP banks there (lane ^ 8: banks {0,1} | {2,3}; lane ^ 7: banks {0,2} | {1,3}), and a DPP add leaves the lanes of
+// masked-off banks untouched, so a fold is TWO `v_add_f32_dpp` into the same register with complementary bank masks
+// instead of two selects and an add.  (Not expressible through the update_dpp builtin: its masked-off lanes take `old`
+// before the add.)  s_nop 1: a DPP source written by the previous VALU instruction needs two wait states, and the
+// hazard recogniser does not look inside inline asm.
+#define PMF_FOLD2(CTRL, M0, M1, Q, A, B) \
+    "v_add_f32_dpp " Q ", " A ", " A " " CTRL " row_mask:0xf bank_mask:" M0 "\n\t" \
+    "v_add_f32_dpp " Q ", " B ", " B " " CTRL " row_mask:0xf bank_mask:" M1 "\n\t"
+__device__ __forceinline__ void fold16_banked(const float (&p)[16], float (&q)[8])
+{
+    asm("s_nop 1\n\t"
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%0", "%8", "%16")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%1", "%9", "%17")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%2", "%10", "%18")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%3", "%11", "%19")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%4", "%12", "%20")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%5", "%13", "%21")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%6", "%14", "%22")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%7", "%15", "%23")
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
+          "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]));
+}
+// twelve inputs: four pairs and four registers that are only folded onto themselves
+__device__ __forceinline__ void fold12_banked(const float (&p)[16], float (&q)[8])
+{
+    asm("s_nop 1\n\t"
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%0", "%8", "%16")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%1", "%9", "%17")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%2", "%10", "%18")
+        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%3", "%11", "%19")
+        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
+          "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]));
+}
+__device__ __forceinline__ void fold8_banked(const float (&q)[8], float (&r)[4])
+{
+    asm("s_nop 1\n\t"
+        PMF_FOLD2("row_half_mirror", "0x5", "0xa", "%0", "%4", "%8")
+        PMF_FOLD2("row_half_mirror", "0x5", "0xa", "%1", "%5", "%9")
+        PMF_FOLD2("row_half_mirror", "0x5", "0xa", "%2", "%6", "%10")
+        PMF_FOLD2("row_half_mirror", "0x5", "0xa", "%3", "%7", "%11")
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+}
+
 // NW_ > 1: a workgroup of NW_ wavefronts shares ONE row, for rows longer than one wave's registers hold (k = 50 fp32,
 // NW_ = 8: up to 1280 nonzeros stay on chip).  Wave w keeps nonzeros [w C, (w + 1) C) of the row in its tile, C =
 // ceil(nnz / NW_) rounded up to a whole step; every wave keeps its own copy of the solver state and runs the same
@@ -336,12 +387,15 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     {
         T q[8], r[4], s2[2];
         constexpr int N8 = N < 8 ? N : 8;
-        if constexpr (G == 16) fold_level<0x128, 8, N>(cls8, p, q);               // row_ror:8           lane ^ 8
+        constexpr bool F32 = std::is_same<T, float>::value;
+        if constexpr (F32 && G == 16 && N == 16) fold16_banked(p, q);             // row_ror:8           lane ^ 8
+        else if constexpr (G == 16) fold_level<0x128, 8, N>(cls8, p, q);
         else {
 #pragma unroll
             for (int i = 0; i < 8; i++) q[i] = p[i];
         }
-        fold_level<0x141, 4, N8>(cls4, q, r);                                      // row_half_mirror     lane ^ 7
+        if constexpr (F32 && N8 == 8) fold8_banked(q, r);                          // row_half_mirror     lane ^ 7
+        else fold_level<0x141, 4, N8>(cls4, q, r);
         constexpr int N4 = N8 < 4 ? N8 : 4;
         fold_level<0x4E, 2, N4>(cls2, r, s2);                                      // quad_perm[2,3,0,1]  lane ^ 2
         constexpr int N2 = N4 < 2 ? N4 : 2;
