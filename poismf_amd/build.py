@@ -5,6 +5,8 @@
 Two translation units per precision (the row kernels + host side, and the rocPRIM-based COO conversion) are
 compiled to object files side by side and linked; only stale objects are rebuilt.
 """
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
@@ -31,11 +33,50 @@ def _stale(out, deps):
     return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
-def build(force=False, verbose=False):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+STAMP = os.path.join(HERE, ".build_stamp")   # hash of the sources + flags the in-tree libraries were built from
+
+
+def _flags():
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
              "-Wno-pass-failed"]
-    flags += os.environ.get("POISMF_HIP_EXTRA_FLAGS", "").split()   # development: e.g. -DPMF_REG_G=8, -DPMF_TIMING
+    return flags + os.environ.get("POISMF_HIP_EXTRA_FLAGS", "").split()   # development: e.g. -DPMF_REG_G=8, -DPMF_TIMING
+
+
+def _source_hash():
+    h = hashlib.sha256(" ".join(_flags()).encode())
+    names = sorted({f for files in UNITS.values() for f in files})
+    for path in [os.path.join(CSRC, f) for f in names] + [HEADER]:
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def up_to_date():
+    """The libraries exist and were built from exactly the sources + flags that are here now.  Object files do not
+    travel with a snapshot of the tree (and file times do not survive one), so this is what decides whether a process
+    on another machine -- or N ranks of one job at once -- may skip the compiler."""
+    try:
+        return all(os.path.exists(lib_path(f)) for f in (False, True)) and open(STAMP).read().strip() == _source_hash()
+    except OSError:
+        return False
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return lib_path(False), lib_path(True)
+    with open(os.path.join(HERE, ".build_lock"), "w") as lock:   # one builder at a time (ranks of a multi-GPU job)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and up_to_date():
+            return lib_path(False), lib_path(True)
+        out = _build_locked(force, verbose)
+        with open(STAMP, "w") as fh:
+            fh.write(_source_hash() + "\n")
+        return out
+
+
+def _build_locked(force, verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = _flags()
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     compiles = []
