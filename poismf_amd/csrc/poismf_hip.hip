@@ -267,7 +267,20 @@ __global__ __launch_bounds__(WAVE* COLSUM_BLOCK_WAVES) void colsum_partial_kerne
     const int w = (int)(threadIdx.x / WAVE);
     T acc[NC];
     PMF_EW acc[i] = (T)0;
-    for (size_t r = (size_t)blockIdx.x * COLSUM_BLOCK_WAVES + w; r < n; r += (size_t)gridDim.x * COLSUM_BLOCK_WAVES) {
+    // four rows in flight per wave (the loop is latency-bound: one 200-byte row per trip); added in row order as before
+    const size_t stride = (size_t)gridDim.x * COLSUM_BLOCK_WAVES;
+    size_t r = (size_t)blockIdx.x * COLSUM_BLOCK_WAVES + w;
+    for (; r + 3 * stride < n; r += 4 * stride) {
+        T v[4][NC];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const T* row = M + (r + u * stride) * (size_t)k;
+            PMF_EW v[u][i] = (lane + WAVE * i < k) ? row[lane + WAVE * i] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { PMF_EW acc[i] += v[u][i]; }
+    }
+    for (; r < n; r += stride) {
         const T* row = M + r * (size_t)k;
         PMF_EW if (lane + WAVE * i < k) acc[i] += row[lane + WAVE * i];
     }
@@ -296,7 +309,17 @@ __global__ __launch_bounds__(WAVE* COLSUM_FINAL_WAVES) void colsum_final_kernel(
     const int w = (int)(threadIdx.x / WAVE);
     T acc[NC];
     PMF_EW acc[i] = (T)0;
-    for (int r = w; r < nw; r += COLSUM_FINAL_WAVES) {
+    int r = w;
+    for (; r + 7 * COLSUM_FINAL_WAVES < nw; r += 8 * COLSUM_FINAL_WAVES) {   // eight loads in flight, same order of adds
+        T v[8][NC];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            PMF_EW v[u][i] = (lane + WAVE * i < k) ? partial[(size_t)(r + u * COLSUM_FINAL_WAVES) * k + lane + WAVE * i] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { PMF_EW acc[i] += v[u][i]; }
+    }
+    for (; r < nw; r += COLSUM_FINAL_WAVES) {
         PMF_EW if (lane + WAVE * i < k) acc[i] += partial[(size_t)r * k + lane + WAVE * i];
     }
     PMF_EW part[w][lane + WAVE * i] = acc[i];
