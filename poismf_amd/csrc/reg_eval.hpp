@@ -158,7 +158,8 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     static constexpr int NW = NW_;
     static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
     static constexpr int KP = 16 * SN;            // elements of a (padded) k-vector in the cross-wave scratch
-    static constexpr int SMEM_BYTES = NW_ > 1 ? NW_ * KP * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) + 16 : 0;
+    static constexpr int RED_BYTES = NW_ * KP * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16);   // one set of cross-wave scratch
+    static constexpr int SMEM_BYTES = NW_ > 1 ? 2 * RED_BYTES + 16 : 0;
     static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
 
     SA t[S][NS];    // the tile
@@ -176,8 +177,8 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     bool act[NC];
     bool slot_on[NS], slot_last[NS];
     unsigned nnz;   // nonzeros of the row held by THIS wave
-    T* red_part;    // NW > 1: [NW][KP] partial gradients, shared by the workgroup
-    double* red_l;  // NW > 1: [NW] partial log-likelihood sums
+    unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
+    int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
     unsigned* ticket_word;
     // interface parity with RowEval (the cached line search is for streamed rows only)
     int pq_cap;
@@ -187,9 +188,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
         lane = lane_id();
-        red_part = (T*)smem;
-        red_l = (double*)(smem + NW * KP * sizeof(T));
-        ticket_word = (unsigned*)(smem + NW * KP * sizeof(T) + 16 * ((NW * 8 + 15) / 16));
+        red_base = smem;
+        red_sel = 0;
+        ticket_word = (unsigned*)(smem + 2 * RED_BYTES);
         F = F_;
         k = geo.k; ldF = geo.ldF; s_load = geo.s_load; zero_row = geo.zero_row;
         g = lane & (G - 1); jg = lane / G; wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
@@ -300,9 +301,15 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
 
     // NW > 1: add up the NW waves' partial results (fixed order; every wave ends with the same bits)
-    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum) const
+    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum)
     {
         if constexpr (NW > 1) {
+            // Alternating scratch sets: a wave may run ahead into the NEXT combine (other set) while a slow wave still
+            // reads this one, but cannot reach the one after that (this set again) before everybody has passed the next
+            // barrier -- so one barrier per evaluation is enough.
+            T* red_part = (T*)(red_base + red_sel * RED_BYTES);
+            double* red_l = (double*)(red_base + red_sel * RED_BYTES + NW * KP * sizeof(T));
+            red_sel ^= 1;
             if (jg == 0) {
 #pragma unroll
                 for (int i = 0; i < NC; i++)
@@ -318,7 +325,6 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
 #pragma unroll
                 for (int i = 0; i < NC; i++) tot[i] += act[i] ? red_part[w * KP + elem[i]] : (T)0;
             }
-            __syncthreads();  // the scratch is free again before anybody starts the next evaluation
         }
     }
     __device__ __forceinline__ void gather(const T* val, unsigned nnz_row)
