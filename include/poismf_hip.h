@@ -181,6 +181,12 @@ POISMF_HIP_API int poismf_hip_half_sweep(poismf_hip_session *s, int which, const
 POISMF_HIP_API void poismf_hip_session_profile(poismf_hip_session *s, int enable);
 POISMF_HIP_API int poismf_hip_session_kernel_time(poismf_hip_session *s, int which, double *total_ms, size_t *launches);
 
+/* Diagnostic: the kernels take log() of the predictions in double (as the reference's C does even in its float build,
+ * ref src/poismf.c:199, :268) with their own implementation of the fdlibm algorithm instead of the device library's.
+ * This runs both on n sample arguments on the current device and reports the largest distance in ulps and the number
+ * of special arguments (+-0, -1, +-inf, NaN) on which they disagree.  Returns 0 on success. */
+POISMF_HIP_API int poismf_hip_selftest_log(size_t n, unsigned long long *worst_ulp, unsigned *mismatched_specials);
+
 /* Number of nonzeros held by this session for half `which` (shard only). */
 POISMF_HIP_API size_t poismf_hip_session_nnz(poismf_hip_session *s, int which);
 

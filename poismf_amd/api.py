@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = (
     "run_poismf", "factors_multiple", "poismf_hip_coo_to_csr_csc", "predict_multiple", "topN", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
     "poismf_hip_session_B", "poismf_hip_session_set_factors", "poismf_hip_session_get_factors",
     "poismf_hip_half_sweep", "poismf_hip_session_profile", "poismf_hip_session_kernel_time",
-    "poismf_hip_session_nnz",
+    "poismf_hip_session_nnz", "poismf_hip_selftest_log",
 )
 
 
@@ -86,6 +86,8 @@ def load_library(use_float):
     lib.poismf_hip_session_kernel_time.restype = i
     lib.poismf_hip_session_nnz.argtypes = [vp, i]
     lib.poismf_hip_session_nnz.restype = sz
+    lib.poismf_hip_selftest_log.argtypes = [sz, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
+    lib.poismf_hip_selftest_log.restype = i
     lib.real_t = r
     _LIBS[key] = lib
     return lib

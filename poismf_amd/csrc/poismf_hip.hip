@@ -242,6 +242,38 @@ __global__ __launch_bounds__(WAVE* REG_NW) __attribute__((amdgpu_waves_per_eu(2,
     sweep_rows<EV, T, EV::NC, METHOD, REG_NW>(a, ev, smem);
 }
 
+// ---- self-test of wave_ops.hpp's d_log against the device library's log --------------------------------------------
+__global__ __launch_bounds__(256) void selftest_log_kernel(unsigned long long n, unsigned long long* worst_ulp, unsigned* mismatched_specials)
+{
+    unsigned long long worst = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        // arguments: a dense sweep of [1/4, 4] (where cancellation is worst), then 2^-1074 .. 2^1023 through bit patterns
+        double x;
+        if (i < n / 2) x = 0.25 + 3.75 * (double)i / (double)(n / 2);
+        else {
+            const unsigned long long j = i - n / 2, m = n - n / 2;
+            const unsigned long long bits = (unsigned long long)((double)j / (double)m * (double)0x7fefffffffffffffULL);
+            x = __builtin_bit_cast(double, bits ? bits : 1ULL);
+        }
+        const double a = d_log(x), b = d_log_lib(x);
+        const long long ia = __builtin_bit_cast(long long, a), ib = __builtin_bit_cast(long long, b);
+        const unsigned long long d = (unsigned long long)(ia > ib ? ia - ib : ib - ia);   // same sign: distance in ulps
+        if ((ia < 0) == (ib < 0)) worst = d > worst ? d : worst;
+        else if (a != b) worst = ~0ULL >> 1;
+    }
+    atomicMax(worst_ulp, worst);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double sp[6] = { 0.0, -0.0, -1.0, __builtin_inf(), -__builtin_inf(), __builtin_nan("") };
+        unsigned bad = 0;
+        for (int q = 0; q < 6; q++) {
+            const double a = d_log(sp[q]), b = d_log_lib(sp[q]);
+            const bool same = (a != a && b != b) || a == b;
+            bad += same ? 0u : 1u;
+        }
+        *mismatched_specials = bad;
+    }
+}
+
 // ---- compact factor -> line-padded copy (the pad columns stay zero from the allocation) --------------------------
 template <class T> __global__ __launch_bounds__(256) void repad_kernel(const T* src, T* dst, size_t n, int k, int ld)
 {
@@ -801,6 +833,25 @@ __attribute__((visibility("default"))) void poismf_hip_debug_timing(unsigned lon
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pmf_timing), z, sizeof(z));
 }
 #endif
+
+// Largest distance in ulps between this library's double log (wave_ops.hpp) and the device library's over n sample
+// arguments, and the number of special arguments (+-0, -1, +-inf, NaN) on which they disagree.
+int poismf_hip_selftest_log(size_t n, unsigned long long* worst_ulp, unsigned* mismatched_specials)
+{
+    unsigned long long* d_w = nullptr;
+    unsigned* d_m = nullptr;
+    HIP_TRY(hipMalloc(&d_w, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&d_m, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d_w, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d_m, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(selftest_log_kernel, dim3(NUM_CU * 8), dim3(256), 0, 0, (unsigned long long)n, d_w, d_m);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(worst_ulp, d_w, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mismatched_specials, d_m, sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d_w);
+    (void)hipFree(d_m);
+    return 0;
+}
 
 int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, const real_t* B_host)
 {

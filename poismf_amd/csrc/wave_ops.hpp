@@ -106,7 +106,45 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 // the float overloads and change the rounding of the surrounding expressions.
 __device__ __forceinline__ double d_abs(double v) { return fabs(v); }
 __device__ __forceinline__ double d_sqrt(double v) { return sqrt(v); }
-__device__ __forceinline__ double d_log(double v) { return log(v); }
+// log in double for the likelihood sums x_j log(pred_j): with ~27 function evaluations per row and half-sweep in CG
+// (and one per evaluation in TNCG) it is the largest single item of those solvers, and the device library's
+// double-double implementation costs 98 VALU instructions.  This is the classic fdlibm scheme (Sun's e_log.c:
+// x = 2^e m, m in [sqrt(1/2), sqrt 2), f = m - 1, s = f / (2 + f), log m = f - f^2/2 + s (f^2/2 + R(s^2)) with a
+// degree-7 minimax R, e ln2 added in a hi/lo split; error < 1 ulp) with the division done as v_rcp_f64 + two Newton
+// steps + one residual correction: 45 instructions.  Zero, negative, infinite and NaN arguments return what log()
+// returns.  poismf_hip_selftest_log() compares it with the device library on the device.
+__device__ __forceinline__ double d_log_lib(double v) { return log(v); }
+__device__ __forceinline__ double d_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int e = __builtin_amdgcn_frexp_exp(x);          // x = m 2^e, m in [1/2, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;                            // m in [sqrt(1/2), sqrt 2)
+    e = low ? e - 1 : e;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    double s = f * y;
+    s = __builtin_fma(__builtin_fma(-d, s, f), y, s);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    double r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    // x = +inf -> +inf; x = 0 -> -inf; x < 0 or NaN -> NaN
+    r = (x == __builtin_inf()) ? x : r;
+    r = (x == 0.0) ? -__builtin_inf() : r;
+    r = (x < 0.0 || x != x) ? __builtin_nan("") : r;
+    return r;
+}
 __device__ __forceinline__ double d_log10(double v) { return log10(v); }
 __device__ __forceinline__ double d_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ double d_max(double a, double b) { return fmax(a, b); }

@@ -124,3 +124,15 @@ def test_register_and_lds_engines_agree(method, tmp_path):
             objs.append(harness.poisson_objective(A, B, csr, harness.auto_defaults("cg", 50)[0], 0.0, 1.0))
         assert abs(objs[0] - objs[1]) <= 2e-2 * abs(objs[1])
         assert H.frac_rows_close(res["reg"].reshape(-1, 50), res["lds"].reshape(-1, 50), 2e-2) >= 0.95
+
+
+def test_double_log_matches_the_device_library():
+    """wave_ops.hpp's d_log (fdlibm scheme, 45 instructions) against the device library's log over 2e7 arguments:
+    a dense sweep of [1/4, 4] and bit patterns from the smallest subnormal to the largest finite double."""
+    import ctypes as C
+    from poismf_amd import api
+    lib = api.load_library(False)
+    worst, bad = C.c_ulonglong(0), C.c_uint(0)
+    assert lib.poismf_hip_selftest_log(20_000_000, C.byref(worst), C.byref(bad)) == 0
+    assert bad.value == 0
+    assert worst.value <= 2, worst.value     # both are < 1 ulp from the true value
