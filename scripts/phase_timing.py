@@ -13,10 +13,11 @@ if os.path.exists(os.path.join(here, "libpoismf_hip_f_timing.so")):
 # otherwise: the in-tree library, built with POISMF_HIP_EXTRA_FLAGS=-DPMF_TIMING python -m poismf_amd.build --force
 maxupd = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 method = sys.argv[2] if len(sys.argv) > 2 else "pg"
+UF = not os.environ.get("PMF_FP64")   # PMF_FP64=1: the double-precision library
 coo = synth.uniform_coo(10 ** 5, 10 ** 5, 10 ** 7, seed=1)
-csr, csc = harness.process_data(coo, True)
-A0, B0 = harness.initialize_matrices(10 ** 5, 10 ** 5, 50, True, 1)
-s = api.Session(csr, csc, 10 ** 5, 10 ** 5, 50, True)
+csr, csc = harness.process_data(coo, UF)
+A0, B0 = harness.initialize_matrices(10 ** 5, 10 ** 5, 50, UF, 1)
+s = api.Session(csr, csc, 10 ** 5, 10 ** 5, 50, UF)
 s.set_factors(A0, B0)
 l2, mu, _ = harness.auto_defaults(method, 50)
 p = s.make_params(method, l2, maxupd=maxupd)
