@@ -1062,9 +1062,13 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         const size_t lds = lds_bytes_per_block(a.geom, sizeof(real_t), L.nw);
         const unsigned waves_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / lds));
         // Waves launched per resident wave slot.  Rows pulled from the queue balance themselves: 2 is enough.  Rows dealt
-        // out statically (PG) come in nnz-descending order, so wave 0 always gets the longest of each round; many short
+        // out statically come in nnz-descending order, so wave 0 always gets the longest of each round; many short
         // waves let the dispatcher even that out (measured on C2, PG(10): 2 -> 1.214 ms, 8 -> 1.165, 32 -> 1.146).
-        unsigned grid_mult = (dynamic || L.reg_S == 0 || L.nw > 1) ? 2 : 32;
+        // The single-wave register kernels are always dealt out this way: with ~1 row per wave the hardware dispatcher IS
+        // the queue (CG fp32 on C2: 3.87 ms with tickets, 3.35 ms without).
+        const bool one_wave_reg = L.reg_S > 0 && L.nw == 1;
+        if (one_wave_reg) a.queue = nullptr;
+        unsigned grid_mult = one_wave_reg ? 32 : 2;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)NUM_CU * waves_per_cu * grid_mult);
         int rc = 1;
