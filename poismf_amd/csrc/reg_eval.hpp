@@ -310,20 +310,38 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             T* red_part = (T*)(red_base + red_sel * RED_BYTES);
             double* red_l = (double*)(red_base + red_sel * RED_BYTES + NW * KP * sizeof(T));
             red_sel ^= 1;
+            // whole 16-byte slots through LDS (the partial sums of elements past k are zero: tile and point are)
+            SA* red_slots = (SA*)red_part;
             if (jg == 0) {
 #pragma unroll
-                for (int i = 0; i < NC; i++)
-                    if (act[i]) red_part[wid * KP + elem[i]] = tot[i];
+                for (int n = 0; n < NS; n++) {
+                    SA v;
+#pragma unroll
+                    for (int e = 0; e < SN; e++) v.v[e] = tot[n * SN + e];
+                    red_slots[wid * 16 + g + G * n] = v;
+                }
             }
             if (lane == 0) red_l[wid] = lsum;
             __syncthreads();
+            SA part[NW][NS];
+            double lp[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {        // all reads in flight, then the sums in wave order
+                lp[w] = red_l[w];
+#pragma unroll
+                for (int n = 0; n < NS; n++) part[w][n] = red_slots[w * 16 + g + G * n];
+            }
             lsum = 0.0;
 #pragma unroll
             for (int i = 0; i < NC; i++) tot[i] = (T)0;
-            for (int w = 0; w < NW; w++) {
-                lsum += red_l[w];
 #pragma unroll
-                for (int i = 0; i < NC; i++) tot[i] += act[i] ? red_part[w * KP + elem[i]] : (T)0;
+            for (int w = 0; w < NW; w++) {
+                lsum += lp[w];
+#pragma unroll
+                for (int n = 0; n < NS; n++) {
+#pragma unroll
+                    for (int e = 0; e < SN; e++) tot[n * SN + e] += act[n * SN + e] ? part[w][n].v[e] : (T)0;
+                }
             }
         }
     }
