@@ -77,7 +77,8 @@ __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t s
 __host__ __device__ inline size_t lds_bytes_per_block(const TileGeom& g, size_t sizeof_real, int nw)
 {
     size_t b = (size_t)nw * lds_bytes_per_wave(g, sizeof_real);
-    if (nw > 1) b += 16 * (((size_t)nw * sizeof(double) + 15) / 16) + (size_t)nw * g.s_load * 16 + 16;  // + row-queue broadcast word
+    // two sets of cross-wave scratch (used alternately: one barrier per evaluation) + the row-queue broadcast word
+    if (nw > 1) b += 2 * (16 * (((size_t)nw * sizeof(double) + 15) / 16) + (size_t)nw * g.s_load * 16) + 16;
     return b;
 }
 
@@ -113,8 +114,8 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     unsigned m_idx[2];
     T m_x[2];
     unsigned meta_c0; // first nonzero of the chunk whose indices / values sit in idxb / xb (0xffffffff: none)
-    T* red_part;      // NW > 1: [NW][s_load * SN] partial gradients, shared by the workgroup
-    double* red_l;    // NW > 1: [NW] partial log-likelihood sums
+    unsigned char* red_base;  // NW > 1: two sets of { [NW] partial log-likelihood sums, [NW][s_load] slots of partial gradients }
+    int red_sel, red_bytes;   // the set the next combine_waves uses; bytes per set
     int wid;
     // launch constants
     const T* F;
@@ -150,8 +151,9 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
         const size_t wave_bytes = lds_bytes_per_wave(geo, sizeof(T));
         unsigned char* p = smem + (size_t)wid * wave_bytes;
-        red_l = (double*)(smem + (size_t)NW * wave_bytes);
-        red_part = (T*)(smem + (size_t)NW * wave_bytes + 16 * ((NW * sizeof(double) + 15) / 16));
+        red_base = smem + (size_t)NW * wave_bytes;
+        red_sel = 0;
+        red_bytes = (int)(16 * ((NW * sizeof(double) + 15) / 16)) + NW * s_load * 16;
         tile = (SA*)p; p += (size_t)cap * s_stride * 16;
         avec = (SA*)p; p += (size_t)s_load * 16;
         xb = (T*)p; p += (((size_t)cap * sizeof(T)) + 15) / 16 * 16;
@@ -460,26 +462,49 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     }
 
     // NW > 1: add up the NW waves' partial results (fixed order; every wave ends with the same bits)
-    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum) const
+    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum)
     {
         if constexpr (NW > 1) {
-            const int kp = s_load * SN;
+            // Alternating scratch sets: a wave may run ahead into the NEXT combine (other set) while a slow wave still
+            // reads this one, but cannot reach the one after that (this set again) before everybody has passed the next
+            // barrier -- one barrier per evaluation.  Whole 16-byte slots go through LDS, all reads are put in flight
+            // before the first add.
+            double* red_l = (double*)(red_base + red_sel * red_bytes);
+            SA* red_slots = (SA*)(red_base + red_sel * red_bytes + 16 * ((NW * sizeof(double) + 15) / 16));
+            red_sel ^= 1;
             if (jg == 0) {
 #pragma unroll
-                for (int i = 0; i < NC; i++)
-                    if (act[i]) red_part[wid * kp + elem[i]] = tot[i];
+                for (int s = 0; s < NS; s++) {
+                    if (slot_on[s]) {
+                        SA v;
+#pragma unroll
+                        for (int e = 0; e < SN; e++) v.v[e] = act[s * SN + e] ? tot[s * SN + e] : (T)0;
+                        red_slots[wid * s_load + slotq[s]] = v;
+                    }
+                }
             }
             if (lane == 0) red_l[wid] = lsum;
             __syncthreads();
+            SA part[NW][NS];
+            double lp[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                lp[w] = red_l[w];
+#pragma unroll
+                for (int s = 0; s < NS; s++) part[w][s] = red_slots[w * s_load + slotq[s]];   // slotq is clamped into the row
+            }
             lsum = 0.0;
 #pragma unroll
             for (int i = 0; i < NC; i++) tot[i] = (T)0;
-            for (int w = 0; w < NW; w++) {
-                lsum += red_l[w];
 #pragma unroll
-                for (int i = 0; i < NC; i++) tot[i] += act[i] ? red_part[w * kp + elem[i]] : (T)0;
+            for (int w = 0; w < NW; w++) {
+                lsum += lp[w];
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+#pragma unroll
+                    for (int e = 0; e < SN; e++) tot[s * SN + e] += act[s * SN + e] ? part[w][s].v[e] : (T)0;
+                }
             }
-            __syncthreads();  // the scratch is free again before anybody starts the next evaluation
         }
     }
 
