@@ -207,11 +207,22 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
 }
 
 // Waves per SIMD the register allocator is asked to make room for: the largest count whose VGPR budget (512 per SIMD
-// lane, granules of 8) holds the tile (TR = 4 S NS registers) plus the solver's working set (PG ~56, CG ~120, TNCG ~150;
-// a few dozen bytes of the idle TNC vectors may spill around the evaluations).
+// lane, granules of 8) holds the tile (TR = 4 S NS registers) plus an allowance for the solver.  The allowances are
+// tuned on C2 (ms per sweep): PG 40 / 56 / 72 -> 1.32 / 1.15 / 1.31; CG 60 / 90 / 120 / 150 -> 3.68 / 3.38 / 3.31 / 3.53;
+// TNCG 30 / 60 / 80 / 100 / 150 / 200 -> 57 / 26 / 17.5 / 16.6 / 18.4 / 20.2 (TNC keeps ~21 k-vectors: below its real
+// need the idle ones spill around the evaluations, which is cheaper than giving up a wave -- up to a point).
+#ifndef PMF_PG_EXTRA
+#define PMF_PG_EXTRA 56
+#endif
+#ifndef PMF_CG_EXTRA
+#define PMF_CG_EXTRA 120
+#endif
+#ifndef PMF_TNC_EXTRA
+#define PMF_TNC_EXTRA 100
+#endif
 constexpr int reg_waves(int tile_regs, int method)
 {
-    const int need = tile_regs + (method == K_PG ? 56 : method == K_CG ? 120 : 150);
+    const int need = tile_regs + (method == K_PG ? PMF_PG_EXTRA : method == K_CG ? PMF_CG_EXTRA : PMF_TNC_EXTRA);
     for (int w : { 8, 6, 5, 4, 3, 2 })
         if ((512 / w) / 8 * 8 >= need) return w;
     return 1;
