@@ -115,22 +115,6 @@ __device__ __forceinline__ void fold16_banked(const float (&p)[16], float (&q)[8
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
           "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]));
 }
-// twelve inputs: four pairs and four registers that are only folded onto themselves
-__device__ __forceinline__ void fold12_banked(const float (&p)[16], float (&q)[8])
-{
-    asm("s_nop 1\n\t"
-        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%0", "%8", "%16")
-        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%1", "%9", "%17")
-        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%2", "%10", "%18")
-        PMF_FOLD2("row_ror:8", "0x3", "0xc", "%3", "%11", "%19")
-        "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
-        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
-          "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]));
-}
 __device__ __forceinline__ void fold8_banked(const float (&q)[8], float (&r)[4])
 {
     asm("s_nop 1\n\t"
@@ -169,13 +153,13 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     // launch constants
     const T* F;
     unsigned zero_row;
-    int k, ldF, s_load, tail;
+    int k, ldF, s_load;
     int lane, g, jg, wid;
     int jlane;      // JG g + jg
     bool cls8, cls4, cls2, cls1;
     int elem[NC];
     bool act[NC];
-    bool slot_on[NS], slot_last[NS];
+    bool slot_on[NS];
     unsigned nnz;   // nonzeros of the row held by THIS wave
     unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
     int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
@@ -196,12 +180,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
         g = lane & (G - 1); jg = lane / G; wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
         jlane = JG * g + jg;
         cls8 = (lane & 8) != 0; cls4 = (lane & 4) != 0; cls2 = (lane & 2) != 0; cls1 = (lane & 1) != 0;
-        tail = k - (s_load - 1) * SN;
 #pragma unroll
         for (int n = 0; n < NS; n++) {
             const int q = g + G * n;
             slot_on[n] = q < s_load;
-            slot_last[n] = q == s_load - 1;
 #pragma unroll
             for (int e = 0; e < SN; e++) {
                 elem[n * SN + e] = q * SN + e;
