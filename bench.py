@@ -118,11 +118,23 @@ def run_gpu(csr, csc, dimA, dimB, rangesA, rangesB, rank, world, device, method,
     be.sess.profile(True)
     dt = timed_sweeps(alt, steps, 0, world, device)
     k_ms = [be.sess.kernel_time(w) for w in (0, 1)]
+    ev_stats = [be.sess.eval_stats(w) for w in (0, 1)]   # (tile passes, passes x nonzeros) of the timed sweeps
     nnz_local = (be.sess.nnz(0), be.sess.nnz(1))
     A, B = be.sess.get_factors()
     be.close()
-    return dict(seconds=dt, kernel_ms=k_ms, nnz_local=nnz_local, finite=bool(np.isfinite(A).all() and np.isfinite(B).all()),
+    return dict(seconds=dt, kernel_ms=k_ms, ev_stats=ev_stats, nnz_local=nnz_local, finite=bool(np.isfinite(A).all() and np.isfinite(B).all()),
                 maxupd=maxupd, l2=l2)
+
+
+def pass_weighted(res, rows, steps, k, s):
+    """what the inner solvers actually read from the on-chip tiles -- sum over rows of (passes over
+    the row's tile) x nonzeros x k x sizeof, per sweep, from counters the row kernels keep while profiling is on."""
+    passes = res["ev_stats"][0][0] + res["ev_stats"][1][0]
+    nnzp = res["ev_stats"][0][1] + res["ev_stats"][1][1]
+    k_ms = (res["kernel_ms"][0][0] + res["kernel_ms"][1][0]) / steps
+    gb = nnzp * k * s / steps / 1e9
+    return {"tile_passes_per_row": passes / steps / max(rows, 1), "on_chip_GB_per_sweep": gb,
+            "on_chip_GBps": gb / (k_ms * 1e-3) if k_ms > 0 else 0.0}
 
 
 def cpu_baseline(csr, csc, dimA, dimB, method, use_float, maxupd):
@@ -247,6 +259,7 @@ def main():
                                  "(dimM+1)*8 per half; traffic = fabric-side bytes per sweep from the PMC passes in profiles/r01/"},
             "results_finite": res["finite"],
         }
+        out["roofline"]["pass_weighted"] = pass_weighted(res, (rangesA[0][1] - rangesA[0][0]) + (rangesB[0][1] - rangesB[0][0]), a.steps, K, s)
         if world == 1 and not a.no_extra:
             extra = {}
             for name, method, uf, mu, st in (("pg_maxupd1_f32", "pg", True, 1, 10), ("cg_f64", "cg", False, None, 3)):
@@ -258,7 +271,7 @@ def main():
                 km = (r["kernel_ms"][0][0] + r["kernel_ms"][1][0]) / st
                 extra[name] = {"value": r["nnz_local"][1] * st / r["seconds"], "unit": "nnz/s", "ms_per_step": r["seconds"] / st * 1e3,
                                "roofline_frac": bb / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_sweep": km,
-                               "finite": r["finite"]}
+                               "finite": r["finite"], "pass_weighted": pass_weighted(r, dimA + dimB, st, K, ss)}
             out["extra"] = extra
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(csr, csc, dimA, dimB, a.method, use_float, a.maxupd)

@@ -181,6 +181,12 @@ POISMF_HIP_API int poismf_hip_half_sweep(poismf_hip_session *s, int which, const
 POISMF_HIP_API void poismf_hip_session_profile(poismf_hip_session *s, int enable);
 POISMF_HIP_API int poismf_hip_session_kernel_time(poismf_hip_session *s, int which, double *total_ms, size_t *launches);
 
+/* While profiling is enabled the row kernels also count, per half (which = 0: B, 1: A) and since the last
+ * poismf_hip_session_profile() call, the passes they made over rows' gathered tiles (one per gradient / function
+ * evaluation of the inner solver, ref src/poismf.c:126-133, :194-273) and the sum over rows of passes x nonzeros --
+ * SURVEY.md 8(d)'s pass-weighted effective traffic is nnz_passes * k * sizeof(real_t). */
+POISMF_HIP_API int poismf_hip_session_eval_stats(poismf_hip_session *s, int which, unsigned long long *tile_passes, unsigned long long *nnz_passes);
+
 /* Diagnostic: the kernels take log() of the predictions in double (as the reference's C does even in its float build,
  * ref src/poismf.c:199, :268) with their own implementation of the fdlibm algorithm instead of the device library's.
  * This runs both on n sample arguments on the current device and reports the largest distance in ulps and the number

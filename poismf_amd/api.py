@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = (
     "run_poismf", "factors_multiple", "poismf_hip_coo_to_csr_csc", "predict_multiple", "topN", "poismf_hip_session_create", "poismf_hip_session_destroy", "poismf_hip_session_A",
     "poismf_hip_session_B", "poismf_hip_session_set_factors", "poismf_hip_session_get_factors",
     "poismf_hip_half_sweep", "poismf_hip_session_profile", "poismf_hip_session_kernel_time",
-    "poismf_hip_session_nnz", "poismf_hip_selftest_log",
+    "poismf_hip_session_nnz", "poismf_hip_selftest_log", "poismf_hip_session_eval_stats",
 )
 
 
@@ -88,6 +88,8 @@ def load_library(use_float):
     lib.poismf_hip_session_nnz.restype = sz
     lib.poismf_hip_selftest_log.argtypes = [sz, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
     lib.poismf_hip_selftest_log.restype = i
+    lib.poismf_hip_session_eval_stats.argtypes = [vp, i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.poismf_hip_session_eval_stats.restype = i
     lib.real_t = r
     _LIBS[key] = lib
     return lib
@@ -359,6 +361,13 @@ class Session:
         if self.lib.poismf_hip_session_kernel_time(self.h, int(which), C.byref(ms), C.byref(n)):
             raise RuntimeError("poismf_hip_session_kernel_time failed")
         return ms.value, n.value
+
+    def eval_stats(self, which):
+        """(tile passes, sum over rows of passes x nonzeros) of this half since profile(True)"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        if self.lib.poismf_hip_session_eval_stats(self.h, int(which), C.byref(a), C.byref(b)):
+            raise RuntimeError("poismf_hip_session_eval_stats failed")
+        return a.value, b.value
 
     def nnz(self, which):
         return self.lib.poismf_hip_session_nnz(self.h, int(which))

@@ -45,6 +45,7 @@ template <class T> struct HalfArgs {
     int reuse_prev, early_stop;
     unsigned* n_unchanged;
     unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
+    unsigned* eval_rows;              // != nullptr (profiling sessions): [local row] += passes over that row's tile
 };
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
@@ -67,6 +68,7 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
         return;
     }
     ev.load_vec(out, x);
+    ev.n_eval = 0;
 
     // per-row constant term: the k-vector itself, or (w != 1) the reference's Bsum_w row
     //   (w - 1) sum_j F_j + Bsum          ref: src/poismf.c:85-123 (adjustment_Bsum)
@@ -103,6 +105,9 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
     }
     ev.store_vec(out, x);
     if (out_p != nullptr) ev.store_vec(out_p, x);
+    // per-row evaluation counts for the pass-weighted effective traffic (a plain read-modify-write: the row
+    // has one owner; a shared counter here costs 4x the kernel time in contention)
+    if (a.eval_rows != nullptr && ev.lane == 0 && ev.wid == 0) a.eval_rows[lrow] += ev.n_eval;
 }
 
 // A wavefront (or, NW > 1, a workgroup of NW wavefronts) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the
@@ -414,6 +419,8 @@ struct Half {
     real_t* d_values = nullptr;
     unsigned* d_perm = nullptr;
     RowDesc* d_desc = nullptr;
+    unsigned* d_eval_rows = nullptr;      // per local row: passes over its tile while profiling (allocated on demand)
+    std::vector<unsigned> row_nnz;        // host copy of the row lengths (for the pass-weighted traffic report)
     std::vector<Bin> bins;
 };
 
@@ -453,6 +460,7 @@ void free_half(Half& h)
     if (h.d_values) (void)hipFree(h.d_values);
     if (h.d_perm) (void)hipFree(h.d_perm);
     if (h.d_desc) (void)hipFree(h.d_desc);
+    if (h.d_eval_rows) (void)hipFree(h.d_eval_rows);
     h = Half();
 }
 
@@ -501,6 +509,8 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     HIP_TRY(hipMemcpyAsync(h.d_indices, lidx.data(), sizeof(unsigned) * h.nnz, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(h.d_values, val + base, sizeof(real_t) * h.nnz, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(h.d_perm, perm.data(), sizeof(unsigned) * nloc, hipMemcpyHostToDevice, stream));
+    h.row_nnz.resize(nloc);
+    for (size_t i = 0; i < nloc; i++) h.row_nnz[i] = (unsigned)(lptr[i + 1] - lptr[i]);
     std::vector<RowDesc> desc(nloc ? nloc : 1);
     for (size_t i = 0; i < nloc; i++) {
         const unsigned long long p0 = lptr[perm[i]];
@@ -889,6 +899,11 @@ void poismf_hip_session_profile(poismf_hip_session* s, int enable)
     for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
     s->prof.clear();
     s->profiling = enable != 0;
+    for (Half& h : s->half) {
+        const size_t n = h.row_end - h.row_begin;
+        if (s->profiling && h.d_eval_rows == nullptr && n > 0 && hipMalloc(&h.d_eval_rows, sizeof(unsigned) * n) != hipSuccess) h.d_eval_rows = nullptr;
+        if (h.d_eval_rows != nullptr) (void)hipMemsetAsync(h.d_eval_rows, 0, sizeof(unsigned) * n, s->stream);
+    }
 }
 
 int poismf_hip_session_kernel_time(poismf_hip_session* s, int which, double* total_ms, size_t* launches)
@@ -905,6 +920,23 @@ int poismf_hip_session_kernel_time(poismf_hip_session* s, int which, double* tot
     }
     *total_ms = tot;
     *launches = n;
+    return 0;
+}
+
+int poismf_hip_session_eval_stats(poismf_hip_session* s, int which, unsigned long long* tile_passes, unsigned long long* nnz_passes)
+{
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    Half& h = s->half[which ? 1 : 0];
+    const size_t n = h.row_end - h.row_begin;
+    *tile_passes = 0;
+    *nnz_passes = 0;
+    if (h.d_eval_rows == nullptr || n == 0) return 0;
+    std::vector<unsigned> ev(n);
+    HIP_TRY(hipMemcpy(ev.data(), h.d_eval_rows, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        *tile_passes += ev[i];
+        *nnz_passes += (unsigned long long)ev[i] * h.row_nnz[i];
+    }
     return 0;
 }
 
@@ -973,6 +1005,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     a.reuse_prev = p->reuse_prev;
     a.early_stop = (p->method == POISMF_TNCG) && p->early_stop && n_unchanged != nullptr;
     a.n_unchanged = s->d_counter;
+    a.eval_rows = s->profiling ? h.d_eval_rows : nullptr;
     if (a.early_stop) HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned), s->stream));
 
     const bool single_pass = is_pg && p->maxupd <= 1 && !weighted;

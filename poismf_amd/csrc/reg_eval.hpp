@@ -161,6 +161,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     bool act[NC];
     bool slot_on[NS];
     unsigned nnz;   // nonzeros of the row held by THIS wave
+    unsigned n_eval; // passes over the tile since the caller last reset it (wave-uniform; reporting only)
     unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
     int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
     unsigned* ticket_word;
@@ -427,6 +428,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     // Same contract as RowEval::eval (store is not supported here: pq_cap == 0)
     template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* = nullptr)
     {
+        n_eval++;
         double lpart = 0.0;
         T part[NC];
 #pragma unroll

@@ -131,6 +131,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     const unsigned* ind;
     const T* val;
     unsigned nnz;
+    unsigned n_eval;  // passes over the row's tile since the caller last reset it (wave-uniform; reporting only)
 #ifdef PMF_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -515,6 +516,7 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     //   store  : if not null, pred_j is also written to store[j] for every nonzero j of the row
     template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
     {
+        n_eval++;
         double lpart = 0.0;
         T part[NC];
 #pragma unroll

@@ -136,3 +136,27 @@ def test_double_log_matches_the_device_library():
     assert lib.poismf_hip_selftest_log(20_000_000, C.byref(worst), C.byref(bad)) == 0
     assert bad.value == 0
     assert worst.value <= 2, worst.value     # both are < 1 ulp from the true value
+
+
+@pytest.mark.parametrize("k", [50, 100])
+def test_tile_pass_counters(k):
+    """While profiling, the row kernels count their passes over each row's tile (pass-weighted traffic).
+    PG makes exactly maxupd passes over every non-empty row -- on the register engine (k = 50: one and eight waves per
+    row) and on the LDS engine (k = 100) alike."""
+    from poismf_amd import api
+    lengths = [1, 40, 100, 161, 700, 1400]
+    csr, csc, A0, B0 = ragged_problem(lengths, 3000, k, True, seed=5)
+    s = api.Session(csr, csc, len(lengths) + 1, 3000, k, True)
+    s.set_factors(A0, B0)
+    p = s.make_params("pg", 1e9, maxupd=3)
+    s.profile(True)
+    step = 1e-7
+    for _ in range(2):
+        step = s.sweep(p, step)
+    nnz_a = np.diff(csr[2].astype(np.int64))
+    nnz_b = np.diff(csc[2].astype(np.int64))
+    for which, nnz in ((1, nnz_a), (0, nnz_b)):
+        passes, nnz_passes = s.eval_stats(which)
+        assert passes == 2 * 3 * int((nnz > 0).sum())
+        assert nnz_passes == 2 * 3 * int(nnz.sum())
+    s.close()
