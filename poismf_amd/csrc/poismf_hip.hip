@@ -555,8 +555,11 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_p
     static const bool no_cache = getenv("POISMF_HIP_CG_NOCACHE") != nullptr;  // testing knob
     // Only for streamed rows: there every line-search trial would otherwise be a fresh gather from L2/HBM
     // (C3 B half: 247 -> 146 ms).  For LDS-resident rows a trial is a cheap pass over the tile already and the
-    // extra q = T.d pass makes the cached variant slightly slower (C2: 10.3 -> 10.9 ms), so they keep the direct one.
-    if (want_pq && !no_cache && !g.resident && (size_t)2 * bin_max_nnz * sizeof(real_t) <= 48 * 1024)
+    // cached variant buys nothing: it halves the passes over the tile (C2 CG fp64: 20 -> 10 per row) and the sweep takes
+    // the same 10.3 ms -- those rows are bound by the solver's chain of k-vector reductions and scalar decisions at one
+    // wave per SIMD, not by the tile passes (POISMF_HIP_CG_CACHE_RESIDENT=1 switches it on for them).
+    static const bool cache_resident = getenv("POISMF_HIP_CG_CACHE_RESIDENT") != nullptr;  // tuning knob
+    if (want_pq && !no_cache && (!g.resident || cache_resident) && (size_t)2 * bin_max_nnz * sizeof(real_t) <= 48 * 1024)
         g.pq_cap = (int)((bin_max_nnz + 15u) / 16u * 16u);
     return g;
 }
