@@ -193,17 +193,28 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
     }
 }
 
+#ifndef PMF_TNC_PREFETCH
+#define PMF_TNC_PREFETCH 0
+#endif
 // LDS-tile engine (row_eval.hpp): one wavefront (= one 64-thread workgroup, so no workgroup barrier is ever needed and
 // the LDS tile is private), or NW wavefronts per row for the long-row path.
 template <class T, int NC, int METHOD, int SL, int NW>
 __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    RowEval<T, NC, SL, NW> ev;
+    // streamed rows prefetch the next chunk's tile (row_eval.hpp, PF); TNC's register budget is spent already
+#ifdef PMF_FORCE_NO_PF
+    constexpr bool PF = false;
+#else
+    // (only in the instances with a compile-time slot count: the generic fp64 CG instance is at 512 registers already,
+    // and the 14 slots in flight pushed it into scratch -- and into wrong results on the k = 200 test)
+    constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
+#endif
+    RowEval<T, NC, SL, NW, PF> ev;
 #ifdef PMF_TIMING
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
 #endif
-    sweep_rows<RowEval<T, NC, SL, NW>, T, NC, METHOD, NW>(a, ev, smem);
+    sweep_rows<RowEval<T, NC, SL, NW, PF>, T, NC, METHOD, NW>(a, ev, smem);
 #ifdef PMF_TIMING
     ev.tacc[5] = __builtin_amdgcn_s_memtime() - t_kernel;
     if (ev.lane == 0 && ev.wid == 0)
@@ -522,11 +533,28 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     return 0;
 }
 
+// Slot counts with a compile-time specialisation: the k values of the BASELINE configs
+// (fp32: k = 49..52 -> 13 slots, k = 97..100 -> 25; fp64: k = 49..50 -> 25, k = 99..100 -> 50).
+#ifdef USE_FLOAT
+constexpr int SPECIAL_SL_A = 13, SPECIAL_SL_B = 25;
+#else
+constexpr int SPECIAL_SL_A = 25, SPECIAL_SL_B = 50;
+#endif
+
+bool prefetch_enabled()
+{
+    static const bool off = getenv("POISMF_HIP_NO_PREFETCH") != nullptr;  // testing knob
+    return !off;
+}
+
 TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_pq)
 {
     TileGeom g;
     g.k = (int)k;
     g.pq_cap = 0;
+    g.prefetch = 0;
+    g.zero_row = 0;
+    g.ldF = (int)k;
     g.s_load = (int)((k * sizeof(real_t) + 15) / 16);
     g.s_stride = g.s_load | 1;
     g.group = g.s_load <= 16 ? 16 : (g.s_load <= 32 ? 32 : 64);
@@ -538,6 +566,11 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_p
     // 128-nonzero chunks 1.46 ms per sweep, 64 or 32: 0.80-0.85 ms)
     unsigned stream_chunk = (unsigned)(14336 / ((size_t)g.s_stride * 16)) / 16 * 16;
     stream_chunk = std::min(128u, std::max(16u, stream_chunk));
+    // with the next chunk's tile requested a chunk ahead (row_eval.hpp, PF) a larger chunk amortises the per-chunk
+    // overhead without exposing its gather: as many nonzeros as the PMF_PRE slots per lane in flight hold
+    // (C3 B half, CG fp64: 32 nonzeros without prefetch 103.9 ms, with 96.6; 48 with prefetch 82.6; 64 without 111.7)
+    if (!single_pass && prefetch_enabled() && ((size_t)g.s_load == (size_t)SPECIAL_SL_A || (size_t)g.s_load == (size_t)SPECIAL_SL_B))
+        stream_chunk = std::max(stream_chunk, std::max(16u, (unsigned)(PMF_PRE * WAVE / g.s_load) / 16 * 16));
     if (const char* e = getenv("POISMF_HIP_STREAM_CHUNK")) stream_chunk = (unsigned)std::max(16, atoi(e));  // tuning knob
     unsigned cap = want;
     g.resident = 1;
@@ -561,6 +594,7 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_p
     static const bool cache_resident = getenv("POISMF_HIP_CG_CACHE_RESIDENT") != nullptr;  // tuning knob
     if (want_pq && !no_cache && (!g.resident || cache_resident) && (size_t)2 * bin_max_nnz * sizeof(real_t) <= 48 * 1024)
         g.pq_cap = (int)((bin_max_nnz + 15u) / 16u * 16u);
+    g.prefetch = (!g.resident && prefetch_enabled()) ? 1 : 0;
     return g;
 }
 
@@ -710,13 +744,6 @@ template <int NS> int launch_reg_steps(hipStream_t stream, int S, int method, co
 constexpr unsigned LONG_ROW_NNZ = 8192;
 constexpr int LONG_NW = 8;
 
-// Slot counts with a compile-time specialisation: the k values of the BASELINE configs
-// (fp32: k = 49..52 -> 13 slots, k = 97..100 -> 25; fp64: k = 49..50 -> 25, k = 99..100 -> 50).
-#ifdef USE_FLOAT
-constexpr int SPECIAL_SL_A = 13, SPECIAL_SL_B = 25;
-#else
-constexpr int SPECIAL_SL_A = 25, SPECIAL_SL_B = 50;
-#endif
 
 // column-sum kernels: elements per lane in the plain lane <-> element layout
 int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : (k <= 512 ? 8 : 0))); }
@@ -1032,7 +1059,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
     for (const Bin& b : h.bins) {
         TileGeom g = plan_geom(s->k, b.max_nnz, single_pass, p->method == POISMF_CG && p->limit_step);
-        if (single_pass) g.resident = 0;  // one pass: "gather once" and "stream" are the same thing
+        if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
         if (reg_ok && b.max_nnz <= reg_nnz_max(p->method)) {
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
             // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
@@ -1058,6 +1085,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
             // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
             g.resident = 0;
+            g.prefetch = prefetch_enabled() ? 1 : 0;
             g.pq_cap = 0;
             int cap = 128;
             for (;;) {

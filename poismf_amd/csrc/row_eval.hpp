@@ -38,6 +38,10 @@ __device__ unsigned long long g_pmf_timing[8];
 #define PMF_T1(slot, v)
 #endif
 
+#ifndef PMF_PRE
+#define PMF_PRE 19
+#endif
+
 template <class T> struct Slot;
 template <> struct Slot<float> {
     static constexpr int N = 4;
@@ -61,6 +65,7 @@ struct TileGeom {
     int pq_cap;    // nonzeros for which the two per-nonzero prediction caches (T.x, T.d) fit in LDS; 0 = no cache
     unsigned zero_row;  // index of the all-zero row the session keeps behind the factor F (= its row count)
     int ldF;       // elements between consecutive rows of the gathered factor (k, or more in the line-padded copy)
+    int prefetch;  // 1: streamed rows keep a second set of index / value buffers (next chunk's tile is requested early)
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t sizeof_real)
@@ -71,6 +76,8 @@ __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t s
     b += (((size_t)g.cap * 4) + 15) / 16 * 16;           // ind_j
     b += 64 * sizeof_real;                               // coef_j of the 64 nonzeros in flight
     b += (((size_t)2 * g.pq_cap * sizeof_real) + 15) / 16 * 16;  // cached predictions p_j = T_j.x and q_j = T_j.d
+    if (g.prefetch)                                      // x_j, ind_j of the NEXT chunk
+        b += (((size_t)g.cap * sizeof_real) + 15) / 16 * 16 + (((size_t)g.cap * 4) + 15) / 16 * 16;
     return b;
 }
 
@@ -93,12 +100,15 @@ __host__ __device__ inline size_t lds_bytes_per_block(const TileGeom& g, size_t 
 // results are combined through LDS in a fixed order behind a workgroup barrier, so all copies stay bit-identical.
 // What it buys is memory-level parallelism: one wave keeps ~8 KiB of gathers in flight (~4 GB/s at ~2 us of
 // latency), eight waves on a CU approach that CU's ~24 GB/s.
-template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
+// PF: streamed rows request the NEXT chunk's factor rows (into registers) before they work on the current chunk and drop
+// them into the tile afterwards, so that a chunk's gather overlaps the previous chunk's two phases.
+template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
     static constexpr int NS = NC / SN;
     static constexpr bool PIPELINED = false;  // sweep_rows: no cross-row prefetch (the LDS tile has one set of index buffers)
+    static constexpr int PRE = PMF_PRE;       // 16-byte slots per lane a prefetched chunk may take (19: 1216 slots = 19 KiB)
     static_assert(NC % SN == 0, "a lane holds whole 16-byte slots");
 
     // LDS carve-out of this wave
@@ -114,6 +124,11 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
     unsigned m_idx[2];
     T m_x[2];
     unsigned meta_c0; // first nonzero of the chunk whose indices / values sit in idxb / xb (0xffffffff: none)
+    unsigned tile_c0; // ... of the chunk whose factor rows sit in the tile          (PF only)
+    unsigned m_c0;    // ... of the chunk whose indices / values sit in m_idx / m_x  (PF only)
+    T* xb2;           // PF: values / indices of the chunk whose tile has been requested
+    unsigned* idxb2;
+    bool pf_on;
     unsigned char* red_base;  // NW > 1: two sets of { [NW] partial log-likelihood sums, [NW][s_load] slots of partial gradients }
     int red_sel, red_bytes;   // the set the next combine_waves uses; bytes per set
     int wid;
@@ -162,6 +177,10 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         coefb = (T*)p; p += 64 * sizeof(T);
         pq_cap = geo.pq_cap;
         pbuf = (T*)p; qbuf = pbuf + pq_cap;
+        p += (((size_t)2 * pq_cap * sizeof(T)) + 15) / 16 * 16;
+        pf_on = PF && geo.prefetch != 0 && !resident && cap <= 2 * WAVE && cap * s_load <= PRE * WAVE;
+        xb2 = (T*)p; p += (((size_t)cap * sizeof(T)) + 15) / 16 * 16;
+        idxb2 = (unsigned*)p;
         ticket_word = (unsigned*)(smem + lds_bytes_per_block(geo, sizeof(T), NW) - 16);
         gj0 = lane / s_load; gt0 = lane % s_load;
         gdj = WAVE / s_load; gdt = WAVE % s_load;
@@ -324,12 +343,83 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
         }
     }
 
+    // ---- PF: the same chunk walk with the next chunk's tile requested one chunk ahead ------------------------------
+    __device__ __forceinline__ unsigned next_chunk(unsigned c0) const
+    {
+        unsigned n = c0 + (unsigned)(NW * cap);
+        if (n >= nnz) n = (unsigned)(wid * cap);       // wrap: the first chunk again, for the next pass over the row
+        return n;
+    }
+    __device__ __forceinline__ int chunk_len(unsigned c0) const { return (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap); }
+    // Makes chunk c0 current (tile + indices + values in LDS; a no-op when the previous visit prefetched it), then puts
+    // the loads of the next chunk's factor rows in flight into `pre` and the indices of the chunk after that into
+    // m_idx / m_x.  Returns the next chunk (== c0: nothing was requested).
+    __device__ __forceinline__ unsigned visit_begin(unsigned c0, int cn, SU (&pre)[PRE])
+    {
+        PMF_T0(tg);
+        if (meta_c0 != c0) { meta_load(c0, cn); meta_c0 = c0; }
+        if (tile_c0 != c0) { gather_tile(cn); tile_c0 = c0; }
+        const unsigned nc0 = next_chunk(c0);
+        if (nc0 == c0) { PMF_T1(0, tg); return c0; }   // single-chunk share: the tile simply stays
+        const int ncn = chunk_len(nc0);
+        if (m_c0 == nc0) {                             // its indices were prefetched during the previous visit
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int j = lane + WAVE * u;
+                if (j < ncn) { idxb2[j] = m_idx[u]; xb2[j] = m_x[u]; }
+            }
+        } else {
+            for (int j = lane; j < ncn; j += WAVE) { idxb2[j] = ind[nc0 + j]; xb2[j] = val[nc0 + j]; }
+        }
+        wave_lds_fence();
+        const unsigned nnc0 = next_chunk(nc0);
+        meta_prefetch(nnc0, chunk_len(nnc0));
+        m_c0 = nnc0;
+        // factor rows of chunk nc0 -> registers (no wait)
+        const int Q = ncn * s_load;
+        int j = gj0, t = gt0;
+#pragma unroll
+        for (int u = 0; u < PRE; u++) {
+            const bool ok = u * WAVE + lane < Q;
+            const int jr = ok ? j : 0, tr = ok ? t : 0;
+            const unsigned col = idxb2[jr];
+            pre[u] = *(const SU*)(F + (size_t)col * (size_t)ldF + (size_t)(tr * SN));
+            t += gdt; j += gdj;
+            if (t >= s_load) { t -= s_load; j += 1; }
+        }
+        PMF_T1(0, tg);
+        return nc0;
+    }
+    // After the current chunk has been processed: the prefetched chunk becomes the tile.
+    __device__ __forceinline__ void visit_end(unsigned c0, unsigned nc0, const SU (&pre)[PRE])
+    {
+        if (nc0 == c0) return;
+        wave_lds_fence();                              // every reader of the current tile / buffers is done
+        const int Q = chunk_len(nc0) * s_load;
+        int j = gj0, t = gt0;
+#pragma unroll
+        for (int u = 0; u < PRE; u++) {
+            const bool ok = u * WAVE + lane < Q;
+            SA w;
+#pragma unroll
+            for (int e = 0; e < SN; e++)  // the last slot of a factor row reads past its end: zero the excess
+                w.v[e] = (e >= 1 && t == s_load - 1 && e >= tail) ? (T)0 : pre[u].v[e];
+            if (ok) tile[j * s_stride + t] = w;
+            t += gdt; j += gdj;
+            if (t >= s_load) { t -= s_load; j += 1; }
+        }
+        T* tx = xb; xb = xb2; xb2 = tx;
+        unsigned* ti = idxb; idxb = idxb2; idxb2 = ti;
+        meta_c0 = nc0; tile_c0 = nc0;
+        wave_lds_fence();
+    }
+
     unsigned* ticket_word;  // NW > 1: one LDS word for the row-queue broadcast (last 16 bytes of the block)
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
     __device__ __forceinline__ void begin_row(const unsigned* ind_, const T* val_, unsigned nnz_)
     {
         ind = ind_; val = val_; nnz = nnz_;
-        meta_c0 = 0xffffffffu;
+        meta_c0 = 0xffffffffu; tile_c0 = 0xffffffffu; m_c0 = 0xffffffffu;
         if (resident && nnz > 0) load_chunk(0, (int)nnz);
     }
 
@@ -525,7 +615,11 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
             unsigned nc0 = 0;
             int ncn = 0;
-            if (!resident) stream_chunk_begin(c0, cn, nc0, ncn);
+            SU pre[PRE];
+            if (!resident) {
+                if (PF && pf_on) nc0 = visit_begin(c0, cn, pre);
+                else stream_chunk_begin(c0, cn, nc0, ncn);
+            }
             for (int jb = 0; jb < cn; jb += WAVE) {
                 PMF_T0(t1);
                 const T pred = pred_lane(jb, cn);
@@ -545,7 +639,10 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
                     PMF_T1(3, t3);
                 }
             }
-            if (!resident) stream_chunk_done(nc0, ncn);
+            if (!resident) {
+                if (PF && pf_on) visit_end(c0, nc0, pre);
+                else stream_chunk_done(nc0, ncn);
+            }
         }
         PMF_T0(t4);
         if constexpr (NW > 1) {
@@ -599,9 +696,16 @@ template <class T, int NC, int SL = 0, int NW = 1> struct RowEval {
             const int cn = (int)((nnz - c0 < (unsigned)cap) ? nnz - c0 : (unsigned)cap);
             unsigned nc0 = 0;
             int ncn = 0;
-            if (!resident) stream_chunk_begin(c0, cn, nc0, ncn);
+            SU pre[PRE];
+            if (!resident) {
+                if (PF && pf_on) nc0 = visit_begin(c0, cn, pre);
+                else stream_chunk_begin(c0, cn, nc0, ncn);
+            }
             for (int jb = 0; jb < cn; jb += WAVE) accumulate<true>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
-            if (!resident) stream_chunk_done(nc0, ncn);
+            if (!resident) {
+                if (PF && pf_on) visit_end(c0, nc0, pre);
+                else stream_chunk_done(nc0, ncn);
+            }
         }
         if constexpr (NW > 1) {
             T tot[NC];
