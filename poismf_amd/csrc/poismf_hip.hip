@@ -566,6 +566,9 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_p
     // 128-nonzero chunks 1.46 ms per sweep, 64 or 32: 0.80-0.85 ms)
     unsigned stream_chunk = (unsigned)(14336 / ((size_t)g.s_stride * 16)) / 16 * 16;
     stream_chunk = std::min(128u, std::max(16u, stream_chunk));
+    // multi-pass solvers: at least 32 nonzeros per chunk while four such tiles still fit a CU's LDS next to everything
+    // else (C5, TNCG fp64 k = 100: 16 -> 32 nonzeros takes the B half from 1091 to 956 ms; 48: 1051)
+    if (!single_pass && (size_t)32 * g.s_stride * 16 <= 28 * 1024) stream_chunk = std::max(stream_chunk, 32u);
     // with the next chunk's tile requested a chunk ahead (row_eval.hpp, PF) a larger chunk amortises the per-chunk
     // overhead without exposing its gather: as many nonzeros as the PMF_PRE slots per lane in flight hold
     // (C3 B half, CG fp64: 32 nonzeros without prefetch 103.9 ms, with 96.6; 48 with prefetch 82.6; 64 without 111.7)
