@@ -257,16 +257,23 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(reg_waves(
 #endif
 }
 
-// The same engine with REG_NW wavefronts per row (reg_eval.hpp, NW_ > 1): rows of up to REG_NW (64 / G) S nonzeros.
-// Two waves per SIMD = one workgroup per CU (two when the tile is small).
-constexpr int REG_NW = 8;
-template <class T, int METHOD, int S, int G, int NS>
-__global__ __launch_bounds__(WAVE* REG_NW) __attribute__((amdgpu_waves_per_eu(2, 4))) void half_sweep_regw_kernel(const HalfArgs<T> a)
+// The same engine with NW = 2, 4 or 8 wavefronts per row (reg_eval.hpp, NW_ > 1): rows of up to NW (64 / G) S nonzeros.
+// The fewest waves whose shares fit their registers are used: every evaluation ends in a barrier and a round trip
+// through LDS, which costs more the more waves take part (C2-shaped PG(10), ns per nonzero and half: 100-nonzero rows on
+// one wave 0.06; 200-nonzero rows 0.137 on eight waves).
+constexpr int REG_NW_MAX = 8;
+constexpr int regw_waves(int tile_regs, int method, int nw)
 {
-    using EV = RegEval<T, S, G, NS, REG_NW>;
+    const int w = reg_waves(tile_regs, method);
+    return nw >= 8 && w < 2 ? 2 : w;   // eight waves are two per SIMD
+}
+template <class T, int METHOD, int S, int G, int NS, int NW>
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(regw_waves(4 * S * NS, METHOD, NW)))) void half_sweep_regw_kernel(const HalfArgs<T> a)
+{
+    using EV = RegEval<T, S, G, NS, NW>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
     EV ev;
-    sweep_rows<EV, T, EV::NC, METHOD, REG_NW>(a, ev, smem);
+    sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
 }
 
 // ---- self-test of wave_ops.hpp's d_log against the device library's log --------------------------------------------
@@ -681,54 +688,71 @@ template <int S, int NS> int launch_reg_method(hipStream_t stream, int method, c
     }
 }
 
-// REG_NW waves per row: the longest share of a row one wave keeps in registers, per solver (CG / TNCG carry more state)
+// Several waves per row: the longest share of a row one wave keeps in registers, per solver (CG / TNCG carry more state)
 constexpr int REGW_WAVE_NNZ_MAX_PG = 160, REGW_WAVE_NNZ_MAX_CG = 128, REGW_WAVE_NNZ_MAX_TNCG = 96;
-unsigned regw_nnz_max(int method)
+unsigned regw_wave_nnz_max(int method)
 {
-    return (unsigned)REG_NW * (method == POISMF_PG ? REGW_WAVE_NNZ_MAX_PG : method == POISMF_CG ? REGW_WAVE_NNZ_MAX_CG : REGW_WAVE_NNZ_MAX_TNCG);
+    return (unsigned)(method == POISMF_PG ? REGW_WAVE_NNZ_MAX_PG : method == POISMF_CG ? REGW_WAVE_NNZ_MAX_CG : REGW_WAVE_NNZ_MAX_TNCG);
 }
-// tile steps for a row of max_nnz nonzeros split over REG_NW waves (each wave's share is rounded up to whole steps)
-int regw_steps_for(unsigned max_nnz)
+unsigned regw_nnz_max(int method) { return (unsigned)REG_NW_MAX * regw_wave_nnz_max(method); }
+// the fewest waves (2, 4, 8) whose shares of a row of max_nnz nonzeros fit
+int regw_waves_for(unsigned max_nnz, int method)
 {
-    const unsigned share = ((max_nnz + REG_NW - 1) / REG_NW + REG_JG - 1) / REG_JG * REG_JG;
+    for (int nw : { 2, 4, 8 })
+        if (max_nnz <= (unsigned)nw * regw_wave_nnz_max(method)) return nw;
+    return 0;
+}
+// tile steps for a row of max_nnz nonzeros split over nw waves (each wave's share is rounded up to whole steps)
+int regw_steps_for(unsigned max_nnz, int nw)
+{
+    const unsigned share = ((max_nnz + (unsigned)nw - 1) / (unsigned)nw + REG_JG - 1) / REG_JG * REG_JG;
     return reg_steps_for(std::max(32u, share));
 }
 
-template <int METHOD, int S, int NS> int launch_regw(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD, int S, int NS, int NW> int launch_regw(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
-    auto kern = half_sweep_regw_kernel<real_t, METHOD, S, REG_G, NS>;
+    auto kern = half_sweep_regw_kernel<real_t, METHOD, S, REG_G, NS, NW>;
     static int occ = 0;  // workgroups per CU
     if (occ == 0) {
         int n = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), WAVE * REG_NW, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), WAVE * NW, 0));
         occ = std::max(1, n);
     }
     const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)NUM_CU * (size_t)occ * grid_mult);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * REG_NW), 0, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW), 0, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <int S, int NS> int launch_regw_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int S, int NS, int NW> int launch_regw_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (S * REG_JG < 32) return 1;
     else switch (method) {
-        case POISMF_PG: return launch_regw<K_PG, S, NS>(stream, a, grid_mult);
+        case POISMF_PG: return launch_regw<K_PG, S, NS, NW>(stream, a, grid_mult);
         case POISMF_CG:
-            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_CG) return launch_regw<K_CG, S, NS>(stream, a, grid_mult);
+            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_CG) return launch_regw<K_CG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
         default:
-            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG) return launch_regw<K_TNCG, S, NS>(stream, a, grid_mult);
+            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG) return launch_regw<K_TNCG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
     }
 }
 
-template <int NS> int launch_regw_steps(hipStream_t stream, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int NS, int NW> int launch_regw_steps_nw(hipStream_t stream, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     switch (S) {
-#define X(NZ) case (NZ) / REG_JG: return launch_regw_method<(NZ) / REG_JG, NS>(stream, method, a, grid_mult);
+#define X(NZ) case (NZ) / REG_JG: return launch_regw_method<(NZ) / REG_JG, NS, NW>(stream, method, a, grid_mult);
         PMF_REG_SIZES(X)
 #undef X
+    }
+    return 1;
+}
+template <int NS> int launch_regw_steps(hipStream_t stream, int nw, int S, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    switch (nw) {
+        case 2: return launch_regw_steps_nw<NS, 2>(stream, S, method, a, grid_mult);
+        case 4: return launch_regw_steps_nw<NS, 4>(stream, S, method, a, grid_mult);
+        case 8: return launch_regw_steps_nw<NS, 8>(stream, S, method, a, grid_mult);
     }
     return 1;
 }
@@ -1075,13 +1099,14 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             continue;
         }
         if (reg_ok && b.max_nnz <= regw_nnz_max(p->method)) {
-            // medium rows: REG_NW waves share a row, each keeps its part of the tile in registers
-            const int S = regw_steps_for(b.max_nnz);
-            if (!launches.empty() && launches.back().nw == REG_NW && launches.back().reg_S >= S &&
+            // medium rows: 2, 4 or 8 waves share a row, each keeps its part of the tile in registers
+            const int nw = regw_waves_for(b.max_nnz, p->method);
+            const int S = regw_steps_for(b.max_nnz, nw);
+            if (!launches.empty() && launches.back().nw == nw && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || b.count < 2048u) && launches.back().begin + launches.back().count == b.begin)
                 launches.back().count += b.count;
             else
-                launches.push_back({ b.begin, b.count, g, REG_NW, S });
+                launches.push_back({ b.begin, b.count, g, nw, S });
             continue;
         }
         if (!no_long && b.max_nnz > long_thr) {
@@ -1156,9 +1181,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (L.reg_S > 0) {
             int rrc;
             if (L.nw > 1) {
-                if constexpr (REG_G == 16) rrc = launch_regw_steps<1>(s->stream, L.reg_S, p->method, a, grid_mult);
-                else rrc = a.geom.s_load <= REG_G ? launch_regw_steps<1>(s->stream, L.reg_S, p->method, a, grid_mult)
-                                                  : launch_regw_steps<2>(s->stream, L.reg_S, p->method, a, grid_mult);
+                if constexpr (REG_G == 16) rrc = launch_regw_steps<1>(s->stream, L.nw, L.reg_S, p->method, a, grid_mult);
+                else rrc = a.geom.s_load <= REG_G ? launch_regw_steps<1>(s->stream, L.nw, L.reg_S, p->method, a, grid_mult)
+                                                  : launch_regw_steps<2>(s->stream, L.nw, L.reg_S, p->method, a, grid_mult);
             } else
             if constexpr (REG_G == 16) rrc = launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult);
             else rrc = a.geom.s_load <= REG_G ? launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult)

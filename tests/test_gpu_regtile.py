@@ -1,6 +1,6 @@
 """The register-tile engine (poismf_amd/csrc/reg_eval.hpp) at its edges, through the C-ABI, against the oracle:
-row lengths on either side of every hand-over (tile steps of 16 nonzeros, one wave -> eight waves at 160, eight waves
--> the LDS engine at 1280 / 1024 / 768), the all-zero row that unused tile steps fetch, the padded gather copies, and
+row lengths on either side of every hand-over (tile steps of 16 nonzeros; one wave -> two -> four -> eight waves per row
+at 160 / 320 / 640 for PG, 128 / 256 / 512 for CG, 96 / 192 / 384 for TNCG; -> the LDS engine at 1280 / 1024 / 768), the all-zero row that unused tile steps fetch, the padded gather copies, and
 agreement with the LDS engine on the same input (POISMF_HIP_NO_REGTILE=1 in a child process).  Needs an MI355X.
 
 Tolerances are those of tests/test_gpu_parity.py."""
@@ -41,8 +41,9 @@ def ragged_problem(lengths, dimB, k, use_float, seed):
     return csr, csc, A0, B0
 
 
-BOUNDARY_LENGTHS = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 162, 255,
-                    256, 257, 383, 384, 385, 511, 512, 513, 767, 768, 769, 1023, 1024, 1025, 1279, 1280, 1281, 1500]
+BOUNDARY_LENGTHS = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 162, 191, 192,
+                    193, 255, 256, 257, 319, 320, 321, 383, 384, 385, 511, 512, 513, 639, 640, 641, 767, 768, 769, 1023, 1024,
+                    1025, 1279, 1280, 1281, 1500]
 
 
 @pytest.mark.parametrize("method,k", [("pg", 50), ("cg", 50), ("tncg", 50), ("tncg", 13), ("pg", 7), ("cg", 13), ("pg", 64), ("pg", 1)])
@@ -50,7 +51,10 @@ def test_row_lengths_on_both_sides_of_every_hand_over(prec, method, k):
     if (not prec) and k > 32:
         pytest.skip("fp64 rows of more than 16 slots never take the register engine")
     csr, csc, A0, B0 = ragged_problem(BOUNDARY_LENGTHS, 4000, k, prec, seed=11)
-    kw = dict(maxupd=40) if method == "tncg" else {}
+    # TNC fp64: enough evaluations to converge each row problem (a truncated run ends wherever its last accepted step
+    # left it, which moves with the summation order by more than the 1e-5 the fp64 objective is held to); fp32 is
+    # checked one-sidedly below and keeps the short budget
+    kw = dict(maxupd=40 if prec else 300) if method == "tncg" else {}
     A, B, args = gpu_run(csr, csc, A0, B0, method, 2, k, **kw)
     Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
     assert not A[-1].any()   # the empty row
