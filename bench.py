@@ -195,6 +195,11 @@ def main():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     build.build()
     device = local_rank if world > 1 else 0
+    # testing aid: several ranks on the GPUs that are there (POISMF_BENCH_SHARE_GPUS=1 with POISMF_BENCH_BACKEND=gloo --
+    # RCCL refuses two ranks on one device) exercises the sharded path with real processes on a 1-GPU box
+    if os.environ.get("POISMF_BENCH_SHARE_GPUS") == "1":
+        device = device % max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("POISMF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device)
     force_dist = os.environ.get("POISMF_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path on a single GPU (testing)
     if world > 1 or force_dist:
@@ -204,7 +209,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{device}"))
         else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"))
+            else:
+                dist.init_process_group(backend)
 
     use_float = not a.fp64
     s = 4 if use_float else 8

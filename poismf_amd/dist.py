@@ -57,7 +57,8 @@ def exchange_shards(full, ranges, rank, group=None):
     if world == 1 and os.environ.get("POISMF_BENCH_FORCE_DIST") != "1":
         return
     sizes = {e - b for b, e in ranges}
-    if len(sizes) == 1 and ranges[0][0] == 0 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)):
+    per_owner = full.is_cuda and dist.get_backend(group) == "gloo"   # gloo has no all_gather_into_tensor on device memory
+    if not per_owner and len(sizes) == 1 and ranges[0][0] == 0 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)):
         b, e = ranges[rank]
         # staged through a copy of the shard rather than gathered in place: the extra copy is the size of one
         # shard (C4 A half: 25 MB, ~10 us of HBM time) and avoids relying on in-place aliasing rules
