@@ -425,7 +425,8 @@ constexpr int MAX_LAUNCHES = 64;  // row bins per half-sweep (16 fine classes + 
 
 struct Bin {
     unsigned begin, count;  // range of the nnz-sorted permutation
-    unsigned max_nnz;
+    unsigned max_nnz;       // longest row actually in the bin (sizes tiles)
+    unsigned cls;           // upper bound of the bin's length class (decides the code path: a function of the row alone)
 };
 
 struct Half {
@@ -507,13 +508,17 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
         for (size_t i = 0; i < nloc; i++) {
             perm[i] = key[i].second;
             const unsigned n = key[i].first;
-            // bin classes: multiples of 16 up to 256 nonzeros, then powers of two.  The LDS tile of a launch
-            // is sized by the longest row of its bin, and LDS is what limits the waves per CU, so fine classes
-            // where most rows live buy occupancy (C2: 100 +- 10 nnz per row -> 7 waves per CU instead of 5).
+            // bin classes: multiples of 16 up to 256 nonzeros, multiples of 64 up to 1280 (the hand-overs between 1, 2, 4
+            // and 8 waves per row fall on those), then powers of two.  The LDS tile of a launch is sized by the longest
+            // row of its bin, and LDS is what limits the waves per CU, so fine classes where most rows live buy
+            // occupancy (C2: 100 +- 10 nnz per row -> 7 waves per CU instead of 5).  Which ENGINE a row takes, and how
+            // many waves share it, is decided by the class bound alone -- never by which other rows happen to be in the
+            // shard -- so a row's arithmetic does not depend on how the matrix is cut into shards.
             unsigned cls;
             if (n <= 256) cls = std::max(16u, (n + 15u) / 16u * 16u);
-            else { cls = 512; while (cls < n) cls <<= 1; }
-            if (h.bins.empty() || cls != h.bins.back().max_nnz) h.bins.push_back({ (unsigned)i, 0u, cls });
+            else if (n <= 1280) cls = (n + 63u) / 64u * 64u;
+            else { cls = 2048; while (cls < n) cls <<= 1; }
+            if (h.bins.empty() || cls != h.bins.back().cls) h.bins.push_back({ (unsigned)i, 0u, 0u, cls });
             h.bins.back().count++;
         }
         // record the true maximum of each bin (first row, since sorted)
@@ -1085,9 +1090,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     unsigned long_thr = LONG_ROW_NNZ;
     if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
     for (const Bin& b : h.bins) {
-        TileGeom g = plan_geom(s->k, b.max_nnz, single_pass, p->method == POISMF_CG && p->limit_step);
+        TileGeom g = plan_geom(s->k, b.cls, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
-        if (reg_ok && b.max_nnz <= reg_nnz_max(p->method)) {
+        if (reg_ok && b.cls <= reg_nnz_max(p->method)) {
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
             // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
             const int S = reg_steps_for(b.max_nnz);
@@ -1098,9 +1103,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 launches.push_back({ b.begin, b.count, g, 1, S });
             continue;
         }
-        if (reg_ok && b.max_nnz <= regw_nnz_max(p->method)) {
+        if (reg_ok && b.cls <= regw_nnz_max(p->method)) {
             // medium rows: 2, 4 or 8 waves share a row, each keeps its part of the tile in registers
-            const int nw = regw_waves_for(b.max_nnz, p->method);
+            const int nw = regw_waves_for(b.cls, p->method);
             const int S = regw_steps_for(b.max_nnz, nw);
             if (!launches.empty() && launches.back().nw == nw && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || b.count < 2048u) && launches.back().begin + launches.back().count == b.begin)
@@ -1109,7 +1114,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 launches.push_back({ b.begin, b.count, g, nw, S });
             continue;
         }
-        if (!no_long && b.max_nnz > long_thr) {
+        if (!no_long && b.cls > long_thr) {
             // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
             // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
             g.resident = 0;

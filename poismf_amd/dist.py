@@ -14,6 +14,7 @@ The per-rank compute is a *backend* with three methods::
 
 The product backend is HipBackend (the C-ABI session, no fallback).  Tests inject their own.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -74,7 +75,10 @@ class HipBackend:
 
     def __init__(self, csr, csc, dimA, dimB, k, use_float, params_kw, shardA, shardB, device):
         torch.cuda.set_device(device)
-        self.stream = torch.cuda.current_stream(device)
+        # A stream of its own, shared by the session's kernels and (through stream_context) by every collective on
+        # the factors: the handle of torch's default stream is 0, which the C-ABI reads as "no stream given" and
+        # answers with a private non-blocking stream -- unordered against the default stream the collectives would run on.
+        self.stream = torch.cuda.Stream(device=device)
         self.sess = api.Session(csr, csc, dimA, dimB, k, use_float, device=device, stream=self.stream.cuda_stream,
                                 shardA=shardA, shardB=shardB)
         self.params = self.sess.make_params(**params_kw)
@@ -85,6 +89,10 @@ class HipBackend:
 
     def half_sweep(self, which, step_size, cnst_div, want_unchanged=False):
         return self.sess.half_sweep(which, self.params, step_size, cnst_div, want_unchanged)
+
+    def stream_context(self):
+        """Run torch operations on the factors (shard exchanges, reductions) in the session's stream order."""
+        return torch.cuda.stream(self.stream)
 
     def factor(self, which):
         return self._A if which else self._B
@@ -116,14 +124,16 @@ class ShardedAlternation:
         if self.method == "tncg" and self.stopped[which]:
             return
         n = self.be.half_sweep(which, self.step, cnst_div, self.early_stop)
-        if dist.is_initialized():
-            exchange_shards(self.be.factor(which), self.ranges[which], self.rank, self.group)
-        if self.early_stop:  # ref: src/poismf.c:395-403, summed over shards
-            t = torch.tensor([float(n)], dtype=torch.float64, device=self.be.factor(which).device)
+        ctx = getattr(self.be, "stream_context", None)
+        with (ctx() if ctx is not None else contextlib.nullcontext()):
             if dist.is_initialized():
-                dist.all_reduce(t, group=self.group)
-            dim = self.dims[0] if which else self.dims[1]
-            self.stopped[which] = (float(t.item()) / float(dim)) >= .95
+                exchange_shards(self.be.factor(which), self.ranges[which], self.rank, self.group)
+            if self.early_stop:  # ref: src/poismf.c:395-403, summed over shards
+                t = torch.tensor([float(n)], dtype=torch.float64, device=self.be.factor(which).device)
+                if dist.is_initialized():
+                    dist.all_reduce(t, group=self.group)
+                dim = self.dims[0] if which else self.dims[1]
+                self.stopped[which] = (float(t.item()) / float(dim)) >= .95
 
     def sweep(self):
         """One full outer iteration; returns False once TNCG early stopping has ended both halves."""
