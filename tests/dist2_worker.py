@@ -16,6 +16,7 @@ from tests import helpers as H  # noqa: E402
 
 def main():
     out, method, use_float = sys.argv[1], sys.argv[2], sys.argv[3] == "f32"
+    early = len(sys.argv) > 4 and sys.argv[4] == "early"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
@@ -25,12 +26,14 @@ def main():
     rangesB = pdist.equal_ranges(dimB, world)
     l2, maxupd, _ = harness.auto_defaults(method, k)
     be = pdist.HipBackend(csr, csc, dimA, dimB, k, use_float,
-                          dict(method=method, l2_reg=l2, maxupd=maxupd, limit_step=True, early_stop=False, reuse_prev=True),
+                          dict(method=method, l2_reg=l2, maxupd=60 if method == "tncg" else maxupd, limit_step=True, early_stop=early,
+                               reuse_prev=True),
                           rangesA[rank], rangesB[rank], 0)
     be.sess.set_factors(A0, B0)
-    alt = pdist.ShardedAlternation(be, rangesA, rangesB, method, l2, 1e-7, dims=(dimA, dimB))
+    alt = pdist.ShardedAlternation(be, rangesA, rangesB, method, l2, 1e-7, early_stop=early, dims=(dimA, dimB))
     for _ in range(3):
-        alt.sweep()
+        if not alt.sweep():
+            break
     torch.cuda.synchronize()
     A, B = be.sess.get_factors()
     if rank == 0:

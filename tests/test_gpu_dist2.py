@@ -18,18 +18,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("method,prec", [("pg", "f32"), ("cg", "f64"), ("cg", "f32")])
-def test_two_processes_reproduce_the_single_process_result(method, prec, tmp_path):
+@pytest.mark.parametrize("method,prec,early", [("pg", "f32", False), ("cg", "f64", False), ("cg", "f32", False),
+                                               ("tncg", "f64", True)])
+def test_two_processes_reproduce_the_single_process_result(method, prec, early, tmp_path):
     out = str(tmp_path / "ranks.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "tests", "dist2_worker.py"), out, method, prec]
+           "--master-port", "29517", os.path.join(ROOT, "tests", "dist2_worker.py"), out, method, prec] + (["early"] if early else [])
     subprocess.run(cmd, check=True, env=env, cwd=ROOT, timeout=900)
     got = np.load(out)
     use_float = prec == "f32"
     csr, csc, A0, B0 = H.small_problem(3000, 2000, 120000, 50, use_float, seed=5, powerlaw=True, empty_rows=(3, 2999))
     l2, maxupd, _ = harness.auto_defaults(method, 50)
-    A, B, _ = gpu_run(csr, csc, A0, B0, method, 3, 50, early_stop=False, reuse_prev=True)
+    kw = dict(maxupd=60) if method == "tncg" else {}
+    A, B, _ = gpu_run(csr, csc, A0, B0, method, 3, 50, early_stop=early, reuse_prev=True, **kw)   # early: the summed counter
     assert np.array_equal(np.isfinite(got["A"]), np.isfinite(A))
     fa, fb = np.isfinite(A), np.isfinite(B)
     assert np.array_equal(got["A"][fa], A[fa]) and np.array_equal(got["B"][fb], B[fb])
