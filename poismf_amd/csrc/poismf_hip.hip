@@ -50,6 +50,17 @@ template <class T> struct HalfArgs {
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
 
+// Translation units.  The row kernels of the three solvers are the bulk of the compile time, so the build compiles this
+// file four times per precision (poismf_amd/build.py): PMF_TU = 0 is the host side (sessions, run_poismf, planning; no
+// row kernel), PMF_TU = K_TNCG / K_CG / K_PG instantiate the row kernels of one solver each and export one function,
+// pmf_launch_one_tu<N>.  Without PMF_TU everything lands in one translation unit.
+#ifndef PMF_TU
+#define PMF_TU -1
+#endif
+constexpr bool tu_has(int kmethod) { return PMF_TU == -1 || PMF_TU == kmethod; }
+#define PMF_TU_HOST (PMF_TU <= 0)
+#define PMF_TU_KERNELS (PMF_TU != 0)
+
 // One row of the sorted order: where its nonzeros start in the shard's CSR arrays, how many, and which row it is.
 struct RowDesc { unsigned p0_lo, p0_hi, nnz, lrow; };
 
@@ -276,6 +287,7 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(regw_w
     sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
 }
 
+#if PMF_TU_HOST
 // ---- self-test of wave_ops.hpp's d_log against the device library's log --------------------------------------------
 __global__ __launch_bounds__(256) void selftest_log_kernel(unsigned long long n, unsigned long long* worst_ulp, unsigned* mismatched_specials)
 {
@@ -307,6 +319,8 @@ __global__ __launch_bounds__(256) void selftest_log_kernel(unsigned long long n,
         *mismatched_specials = bad;
     }
 }
+
+#endif  // PMF_TU_HOST
 
 // ---- compact factor -> line-padded copy (the pad columns stay zero from the allocation) --------------------------
 template <class T> __global__ __launch_bounds__(256) void repad_kernel(const T* src, T* dst, size_t n, int k, int ld)
@@ -630,9 +644,15 @@ template <int NC, int METHOD, int SL, int NW> int launch_bin(hipStream_t stream,
 template <int NC, int SL, int NW = 1> int launch_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
 {
     switch (method) {
-        case POISMF_PG: return launch_bin<NC, K_PG, SL, NW>(stream, a, lds, grid);
-        case POISMF_CG: return launch_bin<NC, K_CG, SL, NW>(stream, a, lds, grid);
-        default: return launch_bin<NC, K_TNCG, SL, NW>(stream, a, lds, grid);
+        case POISMF_PG:
+            if constexpr (tu_has(K_PG)) return launch_bin<NC, K_PG, SL, NW>(stream, a, lds, grid);
+            else return 1;
+        case POISMF_CG:
+            if constexpr (tu_has(K_CG)) return launch_bin<NC, K_CG, SL, NW>(stream, a, lds, grid);
+            else return 1;
+        default:
+            if constexpr (tu_has(K_TNCG)) return launch_bin<NC, K_TNCG, SL, NW>(stream, a, lds, grid);
+            else return 1;
     }
 }
 
@@ -683,12 +703,14 @@ unsigned reg_nnz_max(int method) { return method == POISMF_PG ? REG_NNZ_MAX : me
 template <int S, int NS> int launch_reg_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     switch (method) {
-        case POISMF_PG: return launch_reg<K_PG, S, NS>(stream, a, grid_mult);
+        case POISMF_PG:
+            if constexpr (tu_has(K_PG)) return launch_reg<K_PG, S, NS>(stream, a, grid_mult);
+            else return 1;
         case POISMF_CG:
-            if constexpr (S * REG_JG <= REG_NNZ_MAX_CG) return launch_reg<K_CG, S, NS>(stream, a, grid_mult);
+            if constexpr (tu_has(K_CG) && S * REG_JG <= REG_NNZ_MAX_CG) return launch_reg<K_CG, S, NS>(stream, a, grid_mult);
             else return 1;
         default:
-            if constexpr (S * REG_JG <= REG_NNZ_MAX_TNCG) return launch_reg<K_TNCG, S, NS>(stream, a, grid_mult);
+            if constexpr (tu_has(K_TNCG) && S * REG_JG <= REG_NNZ_MAX_TNCG) return launch_reg<K_TNCG, S, NS>(stream, a, grid_mult);
             else return 1;
     }
 }
@@ -733,12 +755,14 @@ template <int S, int NS, int NW> int launch_regw_method(hipStream_t stream, int 
 {
     if constexpr (S * REG_JG < 32) return 1;
     else switch (method) {
-        case POISMF_PG: return launch_regw<K_PG, S, NS, NW>(stream, a, grid_mult);
+        case POISMF_PG:
+            if constexpr (tu_has(K_PG)) return launch_regw<K_PG, S, NS, NW>(stream, a, grid_mult);
+            else return 1;
         case POISMF_CG:
-            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_CG) return launch_regw<K_CG, S, NS, NW>(stream, a, grid_mult);
+            if constexpr (tu_has(K_CG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_CG) return launch_regw<K_CG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
         default:
-            if constexpr (S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG) return launch_regw<K_TNCG, S, NS, NW>(stream, a, grid_mult);
+            if constexpr (tu_has(K_TNCG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG) return launch_regw<K_TNCG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
     }
 }
@@ -775,12 +799,76 @@ template <int NS> int launch_reg_steps(hipStream_t stream, int S, int method, co
 // Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
 constexpr unsigned LONG_ROW_NNZ = 8192;
 constexpr int LONG_NW = 8;
+constexpr int SLOT_ELEMS = (int)(16 / sizeof(real_t));   // elements per 16-byte slot
 
+
+}  // namespace
+
+// One row-bin launch: everything the planner decided, minus the solver (which selects the translation unit).
+struct OneLaunch {
+    int reg_S, nw, s_load, spl;   // register-engine steps (0: LDS engine), waves per row, slots per factor row, slots per lane
+    bool generic_only;
+    hipStream_t main_stream, bin_stream, long_stream;
+    size_t lds;
+    unsigned grid, grid_mult;
+};
+
+#if PMF_TU_KERNELS
+namespace {
+int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
+{
+    int rc = 1;
+    if (o.reg_S > 0) {
+        if (o.nw > 1) {
+            if constexpr (REG_G == 16) rc = launch_regw_steps<1>(o.main_stream, o.nw, o.reg_S, method, a, o.grid_mult);
+            else rc = o.s_load <= REG_G ? launch_regw_steps<1>(o.main_stream, o.nw, o.reg_S, method, a, o.grid_mult)
+                                        : launch_regw_steps<2>(o.main_stream, o.nw, o.reg_S, method, a, o.grid_mult);
+        } else if constexpr (REG_G == 16) rc = launch_reg_steps<1>(o.bin_stream, o.reg_S, method, a, o.grid_mult);
+        else rc = o.s_load <= REG_G ? launch_reg_steps<1>(o.bin_stream, o.reg_S, method, a, o.grid_mult)
+                                    : launch_reg_steps<2>(o.bin_stream, o.reg_S, method, a, o.grid_mult);
+        return rc;
+    }
+    if (o.nw > 1) {
+        switch (o.spl) {
+            case 1: rc = launch_method<1 * SLOT_ELEMS, 0, LONG_NW>(o.long_stream, method, a, o.lds, o.grid); break;
+            case 2: rc = launch_method<2 * SLOT_ELEMS, 0, LONG_NW>(o.long_stream, method, a, o.lds, o.grid); break;
+        }
+        return rc;
+    }
+    if (!o.generic_only && o.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A>(o.bin_stream, method, a, o.lds, o.grid);
+    else if (!o.generic_only && o.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B>(o.bin_stream, method, a, o.lds, o.grid);
+    else switch (o.spl) {
+        case 1: rc = launch_method<1 * SLOT_ELEMS, 0>(o.bin_stream, method, a, o.lds, o.grid); break;
+        case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(o.bin_stream, method, a, o.lds, o.grid); break;
+    }
+    return rc;
+}
+}  // namespace
+#endif
+#if PMF_TU == 1
+int pmf_launch_one_tu1(int method, const OneLaunch& o, const HalfArgs<real_t>& a) { return launch_one_here(method, o, a); }
+#elif PMF_TU == 2
+int pmf_launch_one_tu2(int method, const OneLaunch& o, const HalfArgs<real_t>& a) { return launch_one_here(method, o, a); }
+#elif PMF_TU == 3
+int pmf_launch_one_tu3(int method, const OneLaunch& o, const HalfArgs<real_t>& a) { return launch_one_here(method, o, a); }
+#endif
+#if PMF_TU == 0
+int pmf_launch_one_tu1(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
+int pmf_launch_one_tu2(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
+int pmf_launch_one_tu3(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
+static int launch_one(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
+{
+    return method == POISMF_PG ? pmf_launch_one_tu3(method, o, a) : method == POISMF_CG ? pmf_launch_one_tu2(method, o, a) : pmf_launch_one_tu1(method, o, a);
+}
+#elif PMF_TU == -1
+static int launch_one(int method, const OneLaunch& o, const HalfArgs<real_t>& a) { return launch_one_here(method, o, a); }
+#endif
+
+namespace {
 
 // column-sum kernels: elements per lane in the plain lane <-> element layout
 int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : (k <= 512 ? 8 : 0))); }
 // row kernels: 16-byte slots per lane (slot layout of row_eval.hpp); 0 = unsupported
-constexpr int SLOT_ELEMS = (int)(16 / sizeof(real_t));
 int slots_per_lane(size_t k)
 {
     const size_t s_load = (k * sizeof(real_t) + 15) / 16;
@@ -811,6 +899,7 @@ int colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t s
 
 }  // namespace
 
+#if PMF_TU_HOST
 extern "C" {
 
 int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream, const real_t* Xr,
@@ -1183,33 +1272,14 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         const int lane_stream = (forked && fork_bins && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
         hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
-        if (L.reg_S > 0) {
-            int rrc;
-            if (L.nw > 1) {
-                if constexpr (REG_G == 16) rrc = launch_regw_steps<1>(s->stream, L.nw, L.reg_S, p->method, a, grid_mult);
-                else rrc = a.geom.s_load <= REG_G ? launch_regw_steps<1>(s->stream, L.nw, L.reg_S, p->method, a, grid_mult)
-                                                  : launch_regw_steps<2>(s->stream, L.nw, L.reg_S, p->method, a, grid_mult);
-            } else
-            if constexpr (REG_G == 16) rrc = launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult);
-            else rrc = a.geom.s_load <= REG_G ? launch_reg_steps<1>(bin_stream, L.reg_S, p->method, a, grid_mult)
-                                              : launch_reg_steps<2>(bin_stream, L.reg_S, p->method, a, grid_mult);
-            if (rrc) return 1;
-            continue;
-        }
-        if (L.nw > 1) {
-            switch (slots_per_lane(s->k)) {
-                case 1: rc = launch_method<1 * SLOT_ELEMS, 0, LONG_NW>(long_stream, p->method, a, lds, grid); break;
-                case 2: rc = launch_method<2 * SLOT_ELEMS, 0, LONG_NW>(long_stream, p->method, a, lds, grid); break;
-            }
-            if (rc) return 1;
-            continue;
-        }
-        static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
-        if (!generic_only && a.geom.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A>(bin_stream, p->method, a, lds, grid);
-        else if (!generic_only && a.geom.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B>(bin_stream, p->method, a, lds, grid);
-        else switch (slots_per_lane(s->k)) {
-            case 1: rc = launch_method<1 * SLOT_ELEMS, 0>(bin_stream, p->method, a, lds, grid); break;
-            case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(bin_stream, p->method, a, lds, grid); break;
+        {
+            OneLaunch o;
+            o.reg_S = L.reg_S; o.nw = L.nw; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
+            static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
+            o.generic_only = generic_only;
+            o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
+            o.lds = lds; o.grid = grid; o.grid_mult = grid_mult;
+            rc = launch_one(p->method, o, a);
         }
         if (rc) return 1;
     }
@@ -1392,3 +1462,4 @@ int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* 
 }
 
 }  // extern "C"
+#endif  // PMF_TU_HOST
