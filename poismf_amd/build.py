@@ -44,6 +44,13 @@ def _stale(out, deps):
 STAMP = os.path.join(HERE, ".build_stamp")   # hash of the sources + flags the in-tree libraries were built from
 
 
+def _units():
+    """The -DPMF_TIMING development build keeps its phase timers in one device-side array, so it stays one translation unit."""
+    if "-DPMF_TIMING" in os.environ.get("POISMF_HIP_EXTRA_FLAGS", "").split():
+        return {"poismf_hip_all": (_ROW, []), "coo_convert": UNITS["coo_convert"], "serve": UNITS["serve"]}
+    return UNITS
+
+
 def _flags():
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
              "-Wno-pass-failed"]
@@ -51,8 +58,8 @@ def _flags():
 
 
 def _source_hash():
-    h = hashlib.sha256((" ".join(_flags()) + repr(sorted((u, f) for u, (_, f) in UNITS.items()))).encode())
-    names = sorted({f for files, _ in UNITS.values() for f in files})
+    h = hashlib.sha256((" ".join(_flags()) + repr(sorted((u, f) for u, (_, f) in _units().items()))).encode())
+    names = sorted({f for files, _ in _units().values() for f in files})
     for path in [os.path.join(CSRC, f) for f in names] + [HEADER]:
         with open(path, "rb") as fh:
             h.update(os.path.basename(path).encode() + b"\0" + fh.read())
@@ -89,7 +96,7 @@ def _build_locked(force, verbose):
         flags.append("-Rpass-analysis=kernel-resource-usage")
     compiles = []
     for use_float in (False, True):
-        for unit, (files, unit_flags) in UNITS.items():
+        for unit, (files, unit_flags) in _units().items():
             deps = [os.path.join(CSRC, f) for f in files] + [HEADER]
             obj = _obj_path(unit, use_float)
             if force or _stale(obj, deps):
@@ -102,7 +109,7 @@ def _build_locked(force, verbose):
             raise subprocess.CalledProcessError(p.returncode, cmd)
     for use_float in (False, True):
         out = lib_path(use_float)
-        objs = [_obj_path(u, use_float) for u in UNITS]
+        objs = [_obj_path(u, use_float) for u in _units()]
         if force or _stale(out, objs):
             cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
             if verbose:

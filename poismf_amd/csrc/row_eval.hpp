@@ -637,6 +637,8 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
                     PMF_T0(t3);
                     accumulate<false>(jb, cn - jb < WAVE ? cn - jb : WAVE, part);
                     PMF_T1(3, t3);
+                } else {
+                    PMF_T1(2, t2);   // function evaluations: the log is the "coefficient" step
                 }
             }
             if (!resident) {
