@@ -38,6 +38,13 @@ __device__ unsigned long long g_pmf_timing[8];
 #define PMF_T1(slot, v)
 #endif
 
+// unroll depths of the two LDS phases (slots per block in phase 1, steps per block in phase 2)
+#ifndef PMF_P1_BLOCK
+#define PMF_P1_BLOCK 8
+#endif
+#ifndef PMF_P2_BLOCK
+#define PMF_P2_BLOCK 16
+#endif
 #ifndef PMF_PRE
 #define PMF_PRE 19
 #endif
@@ -457,12 +464,13 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
         // Blocks of 8 slots: all 16 LDS reads of a block are in flight before the first FMA (at 1-2 waves per
         // SIMD nothing else hides LDS latency), then one masked block for the 0-7 slots left over.
         int t = 0;
-        for (; t + 8 <= s_load; t += 8) {
-            SA tv[8], av[8];
+        constexpr int PB = PMF_P1_BLOCK;
+        for (; t + PB <= s_load; t += PB) {
+            SA tv[PB], av[PB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { tv[u] = row[t + u]; av[u] = avec[t + u]; }
+            for (int u = 0; u < PB; u++) { tv[u] = row[t + u]; av[u] = avec[t + u]; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < PB; u++) {
 #pragma unroll
                 for (int h = 0; h < H; h++)
                     p[h] = __builtin_elementwise_fma((V2){ tv[u].v[2 * h], tv[u].v[2 * h + 1] },
@@ -470,14 +478,14 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
             }
         }
         {
-            const int rem = s_load - t;  // 0..7, wave-uniform
-            SA tv[7], av[7];
+            const int rem = s_load - t;  // 0..PB-1, wave-uniform
+            SA tv[PB - 1], av[PB - 1];
 #pragma unroll
-            for (int u = 0; u < 7; u++) {
+            for (int u = 0; u < PB - 1; u++) {
                 if (u < rem) { tv[u] = row[t + u]; av[u] = avec[t + u]; }
             }
 #pragma unroll
-            for (int u = 0; u < 7; u++) {
+            for (int u = 0; u < PB - 1; u++) {
                 if (u < rem) {
 #pragma unroll
                     for (int h = 0; h < H; h++)
@@ -531,8 +539,12 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
         const int full = cnt / JG;              // steps in which every group has a nonzero (wave-uniform)
         const int steps = (cnt + JG - 1) / JG;
         int it = 0;
-        for (; it + 16 <= full; it += 16) accumulate_block<UNIT, 16, false>(base, it, cnt, part);
-        if (it + 8 <= full) { accumulate_block<UNIT, 8, false>(base, it, cnt, part); it += 8; }
+        if constexpr (PMF_P2_BLOCK >= 16) {
+            for (; it + 16 <= full; it += 16) accumulate_block<UNIT, 16, false>(base, it, cnt, part);
+            if (it + 8 <= full) { accumulate_block<UNIT, 8, false>(base, it, cnt, part); it += 8; }
+        } else {
+            for (; it + 8 <= full; it += 8) accumulate_block<UNIT, 8, false>(base, it, cnt, part);
+        }
         if (it + 4 <= full) { accumulate_block<UNIT, 4, false>(base, it, cnt, part); it += 4; }
         if (it < steps) accumulate_block<UNIT, 4, true>(base, it, cnt, part);   // <= 3 full steps + a partial one
     }
