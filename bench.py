@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- nonzeros/sec per full A+B sweep of the factor-update hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--method pg|cg|tncg] [--maxupd M] [--no-cpu] [--no-extra]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--method pg|cg|tncg] [--maxupd M] [--fp64] [--no-cpu] [--no-extra]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one full outer iteration (B half + A half, column sums and -- multi-GPU -- the shard
-all-gathers included) on synthetic data that is already resident in HBM when the timed region starts.
+A "step" is one full outer iteration (B half + A half, column sums and -- multi-GPU -- the shard exchanges
+included) on synthetic data that is already resident in HBM when the timed region starts.
 
-N = 1  : BASELINE config C2 -- uniform 1e5 x 1e5, 1e7 triplets (9 994 947 nnz after duplicate summing),
-         k = 50, method = pg, fp32, the reference's Python defaults (l2 1e9, step 1e-7, maxupd 10).
-N > 1  : weak scaling of that shape: every rank owns one 1e5-row block of A (1e7 triplets, seed 1 + rank),
-         so X is (N*1e5) x 1e5 with ~N*1e7 nnz -- N = 8 is roughly BASELINE config C4.  B rows are split
-         evenly; after each half the updated shard is all-gathered over RCCL.
+Workload (every N): the matrix BASELINE.json quotes the metric on -- uniform 1 000 000 x 100 000, 1e8 triplets
+(seed 1; ~9.995e7 nonzeros after duplicate summing), k = 50 (configs C3 / C4).  The headline line is method = pg,
+fp32, the reference's Python defaults (l2 1e9, step 1e-7, maxupd 10); at N = 1 `extra` carries the other points of
+the metric on the SAME matrix, each with its own roofline block: pg with maxupd = 1 (the bandwidth point, R's
+default), pg with hyper-parameters that keep the factors finite (same work per sweep), and cg fp64 (config C3).
+N > 1 is STRONG scaling of that one matrix: A rows and B rows are cut into per-rank ranges with balanced nonzero
+counts, every rank builds its CSR / CSC shards on its GPU from the triplets, both factors are replicated, and
+after each half the updated rows go to every peer over RCCL (poismf_amd/dist.py).
 
-Rank 0 prints ONE JSON line (see the driver contract); `roofline` prices the row-update kernel against
-HBM peak with SURVEY.md 8(d)'s algorithmic bytes, `cpu_baseline` is the compiled reference (oracle/_ref,
-kind "reference") timed on this box's host cores on the same matrix.
+Rank 0 prints ONE JSON line (see the driver contract); `roofline` prices the row-update kernels against HBM
+peak with SURVEY.md 8(d)'s algorithmic bytes, `cpu_baseline` is the compiled reference (oracle/_ref, kind
+"reference") timed on this box's host cores on the same matrix (steady state: the difference of a 2-iteration
+and a 1-iteration run).
 """
 import argparse
 import json
@@ -30,7 +34,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import scipy.sparse as sp  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -38,7 +41,12 @@ from poismf_amd import api, build, harness, synth  # noqa: E402
 from poismf_amd import dist as pdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-BLOCK_ROWS, DIMB, BLOCK_NNZ, K = 10 ** 5, 10 ** 5, 10 ** 7, 50
+WORKLOADS = {
+    # name: (dimA, dimB, triplets)
+    "C4": (10 ** 6, 10 ** 5, 10 ** 8),   # = C3's matrix; the one BASELINE.json's metric is quoted on
+    "C2": (10 ** 5, 10 ** 5, 10 ** 7),   # development only
+}
+K = 50
 
 
 def algorithmic_bytes_half(nnz, dimM, k, s):
@@ -46,46 +54,17 @@ def algorithmic_bytes_half(nnz, dimM, k, s):
     return nnz * (4 + s + k * s) + 2 * dimM * k * s + (dimM + 1) * 8
 
 
-def build_inputs(rank, world, use_float, BLOCK_ROWS=BLOCK_ROWS, DIMB=DIMB, BLOCK_NNZ=BLOCK_NNZ):
-    """Returns (csr, csc, dimA, dimB, rangesA, rangesB) with only this rank's shards populated in the
-    whole-matrix-shaped CSR / CSC arrays the C-ABI takes (tests/test_bench_inputs.py checks that the shards of all
-    ranks tile the CSR / CSC of the stacked blocks exactly)."""
-    dt = np.float32 if use_float else np.float64
-    dimA, dimB = BLOCK_ROWS * world, DIMB
-    rangesA = [(r * BLOCK_ROWS, (r + 1) * BLOCK_ROWS) for r in range(world)]
-    rangesB = pdist.equal_ranges(dimB, world)
+def plan_ranges(trip, world):
+    """Per-rank row ranges of A and of B, identical on every rank (computed from the seeded triplets)."""
+    dimA, dimB = trip.shape
     if world == 1:
-        coo = synth.uniform_coo(dimA, dimB, BLOCK_NNZ, seed=1)
-        csr, csc = harness.process_data(coo, use_float)
-        return csr, csc, dimA, dimB, rangesA, rangesB
-    # CSR: own block only, placed at its global row offset
-    own = sp.csr_matrix(synth.uniform_coo(BLOCK_ROWS, dimB, BLOCK_NNZ, seed=1 + rank))
-    own.sum_duplicates(); own.sort_indices()
-    ptr = np.zeros(dimA + 1, np.uint64)
-    r0 = rank * BLOCK_ROWS
-    ptr[r0:r0 + BLOCK_ROWS + 1] = own.indptr
-    ptr[r0 + BLOCK_ROWS + 1:] = own.indptr[-1]
-    csr = (own.data.astype(dt), own.indices.astype(np.uint64), ptr)
-    # CSC: this rank's column range of EVERY block
-    c0, c1 = rangesB[rank]
-    rows, cols, vals = [], [], []
-    for r in range(world):
-        blk = synth.uniform_coo(BLOCK_ROWS, dimB, BLOCK_NNZ, seed=1 + r)
-        m = (blk.col >= c0) & (blk.col < c1)
-        rows.append(blk.row[m] + r * BLOCK_ROWS); cols.append(blk.col[m] - c0); vals.append(blk.data[m])
-    sub = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(dimA, c1 - c0))
-    sub.sum_duplicates(); sub.sort_indices()
-    cptr = np.zeros(dimB + 1, np.uint64)
-    cptr[c0:c1 + 1] = sub.indptr
-    cptr[c1 + 1:] = sub.indptr[-1]
-    csc = (sub.data.astype(dt), sub.indices.astype(np.uint64), cptr)
-    return csr, csc, dimA, dimB, rangesA, rangesB
+        return [(0, dimA)], [(0, dimB)]
+    return (pdist.choose_ranges(np.bincount(trip.row, minlength=dimA), world),
+            pdist.choose_ranges(np.bincount(trip.col, minlength=dimB), world))
 
 
-def timed_sweeps(alt, steps, warmup, world, device):
+def timed_sweeps(alt, steps, device):
     multi = dist.is_initialized()
-    for _ in range(warmup):
-        alt.sweep()
     if multi:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -104,41 +83,98 @@ def timed_sweeps(alt, steps, warmup, world, device):
     return dt
 
 
-def run_gpu(csr, csc, dimA, dimB, rangesA, rangesB, rank, world, device, method, use_float, maxupd, steps, warmup, seed=1):
-    l2, mu, _ = harness.auto_defaults(method, K)
-    maxupd = mu if maxupd is None else maxupd
-    A0, B0 = harness.initialize_matrices(dimA, dimB, K, use_float, seed)
-    be = pdist.HipBackend(csr, csc, dimA, dimB, K, use_float,
-                          dict(method=method, l2_reg=l2, maxupd=maxupd, limit_step=True, early_stop=False, reuse_prev=True),
-                          rangesA[rank], rangesB[rank], device)
-    be.sess.set_factors(A0, B0)
-    alt = pdist.ShardedAlternation(be, rangesA, rangesB, method, l2, 1e-7, dims=(dimA, dimB))
-    for _ in range(warmup):
-        alt.sweep()
-    be.sess.profile(True)
-    dt = timed_sweeps(alt, steps, 0, world, device)
-    k_ms = [be.sess.kernel_time(w) for w in (0, 1)]
-    ev_stats = [be.sess.eval_stats(w) for w in (0, 1)]   # (tile passes, passes x nonzeros) of the timed sweeps
-    nnz_local = (be.sess.nnz(0), be.sess.nnz(1))
-    A, B = be.sess.get_factors()
-    be.close()
-    return dict(seconds=dt, kernel_ms=k_ms, ev_stats=ev_stats, nnz_local=nnz_local, finite=bool(np.isfinite(A).all() and np.isfinite(B).all()),
-                maxupd=maxupd, l2=l2)
+class Job:
+    """One session (one precision) on this rank's shards, reusable for several (method, hyper-parameter) runs."""
+
+    def __init__(self, trip, rangesA, rangesB, rank, device, use_float, segmentsA):
+        self.trip, self.rangesA, self.rangesB, self.rank, self.device, self.use_float = trip, rangesA, rangesB, rank, device, use_float
+        self.dimA, self.dimB = trip.shape
+        t0 = time.perf_counter()
+        self.be = pdist.HipBackend(None, None, self.dimA, self.dimB, K, use_float,
+                                   dict(method="pg", l2_reg=1.0), rangesA[rank], rangesB[rank], device, coo=trip,
+                                   segments=(1, segmentsA))
+        torch.cuda.synchronize(device)
+        self.setup_s = time.perf_counter() - t0
+        self.A0, self.B0 = harness.initialize_matrices(self.dimA, self.dimB, K, use_float, 1)
+        self.nnz_local = (self.be.sess.nnz(0), self.be.sess.nnz(1))
+
+    def run(self, method, maxupd, steps, warmup, l2=None, step0=1e-7, profile_steps=None):
+        """warmup + `steps` timed sweeps with profiling OFF (the product configuration), then a separate profiled pass
+        (HIP events around the row-kernel launches of each half, per-row pass counters) of `profile_steps` sweeps from
+        the same starting point for the kernel time and the pass-weighted traffic."""
+        l2d, mu, _ = harness.auto_defaults(method, K)
+        l2 = l2d if l2 is None else l2
+        maxupd = mu if maxupd is None else maxupd
+        sess = self.be.sess
+        self.be.params = sess.make_params(method=method, l2_reg=l2, maxupd=maxupd, limit_step=True, early_stop=False, reuse_prev=True)
+        dims = (self.dimA, self.dimB)
+
+        def fresh():
+            sess.set_factors(self.A0, self.B0)
+            return pdist.ShardedAlternation(self.be, self.rangesA, self.rangesB, method, l2, step0, dims=dims)
+
+        alt = fresh()
+        for _ in range(warmup):
+            alt.sweep()
+        dt = timed_sweeps(alt, steps, self.device)
+        A, B = sess.get_factors()
+        finite = bool(np.isfinite(A).all() and np.isfinite(B).all())
+        del A, B
+        psteps = profile_steps or min(steps, 5)
+        alt = fresh()
+        for _ in range(warmup):
+            alt.sweep()
+        sess.profile(True)
+        for _ in range(psteps):
+            alt.sweep()
+        k_ms = [sess.kernel_time(w) for w in (0, 1)]
+        ev_stats = [sess.eval_stats(w) for w in (0, 1)]
+        plan = [sess.plan(w) for w in (0, 1)]
+        sess.profile(False)
+        return dict(method=method, maxupd=maxupd, l2=l2, step0=step0, steps=steps, seconds=dt, finite=finite, psteps=psteps,
+                    kernel_ms=k_ms, ev_stats=ev_stats, plan=plan)
+
+    def close(self):
+        self.be.close()
 
 
-def pass_weighted(res, rows, steps, k, s):
-    """what the inner solvers actually read from the on-chip tiles -- sum over rows of (passes over
-    the row's tile) x nonzeros x k x sizeof, per sweep, from counters the row kernels keep while profiling is on."""
+def roofline_block(job, res, traffic_key=None):
+    """HBM roofline of the row-update kernels of one run, this rank's launches: algorithmic bytes of its two shards per
+    sweep / the summed duration of their launches per sweep."""
+    s = 4 if job.use_float else 8
+    rA, rB = job.rangesA[job.rank], job.rangesB[job.rank]
+    b_half = [algorithmic_bytes_half(job.nnz_local[0], rB[1] - rB[0], K, s), algorithmic_bytes_half(job.nnz_local[1], rA[1] - rA[0], K, s)]
+    k_ms_half = [res["kernel_ms"][w][0] / res["psteps"] for w in (0, 1)]
+    k_ms = sum(k_ms_half)
+    achieved = sum(b_half) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    rows = (rA[1] - rA[0]) + (rB[1] - rB[0])
     passes = res["ev_stats"][0][0] + res["ev_stats"][1][0]
     nnzp = res["ev_stats"][0][1] + res["ev_stats"][1][1]
-    k_ms = (res["kernel_ms"][0][0] + res["kernel_ms"][1][0]) / steps
-    gb = nnzp * k * s / steps / 1e9
-    return {"tile_passes_per_row": passes / steps / max(rows, 1), "on_chip_GB_per_sweep": gb,
-            "on_chip_GBps": gb / (k_ms * 1e-3) if k_ms > 0 else 0.0}
+    gb = nnzp * K * s / res["psteps"] / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if traffic_key and os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(traffic_key)
+        except Exception:
+            traffic = None
+    # the launch with the most rows x tile steps names the dominant instance
+    launches = [(n, r) for w in (0, 1) for n, r in res["plan"][w]]
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "row-update kernels of one sweep: " + "; ".join(f"{n} x{r} rows" for n, r in launches),
+            "kernel_ms_per_sweep": k_ms, "kernel_ms_B_half": k_ms_half[0], "kernel_ms_A_half": k_ms_half[1],
+            "algorithmic_bytes_per_sweep": int(sum(b_half)), "half_sweeps_profiled": int(res["kernel_ms"][0][1] + res["kernel_ms"][1][1]),
+            "pass_weighted": {"tile_passes_per_row": passes / res["psteps"] / max(rows, 1), "on_chip_GB_per_sweep": gb,
+                              "on_chip_GBps": gb / (k_ms * 1e-3) if k_ms > 0 else 0.0},
+            "note": "achieved = algorithmic bytes of one sweep's row-kernel launches / their summed duration, measured in a separate "
+                    "profiled pass (HIP events on the session stream around each half's launches; launches are serial, so this equals "
+                    "sum(Calls x AverageNs) of the half_sweep_* rows of the rocprofv3 kernel stats under profiles/); bytes = "
+                    "nnz*(4+s+k*s) + 2*dimM*k*s + (dimM+1)*8 per half; traffic = fabric-side bytes per sweep from separate PMC passes"}
 
 
-def cpu_baseline(csr, csc, dimA, dimB, method, use_float, maxupd):
-    """The compiled reference (oracle/_ref) on this box's host cores, same matrix, 2 full sweeps."""
+def cpu_baseline(trip, method, use_float, maxupd):
+    """The compiled reference (oracle/_ref) on this box's host cores, same matrix: steady-state seconds per sweep =
+    t(2 outer iterations) - t(1 outer iteration)."""
     from oracle import bindings
     try:
         import psutil
@@ -149,12 +185,18 @@ def cpu_baseline(csr, csc, dimA, dimB, method, use_float, maxupd):
     lib = bindings.Reference(use_float) if kind == "reference" else bindings.Oracle(use_float)
     l2, mu, _ = harness.auto_defaults(method, K)
     maxupd = mu if maxupd is None else maxupd
-    A, B = harness.initialize_matrices(dimA, dimB, K, use_float, 1)
-    sweeps = 2
-    t0 = time.perf_counter()
-    lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], l2, 0.0, 1.0, 1e-7, method, True, sweeps, maxupd,
-                   False, True, True, cores)
-    dt = time.perf_counter() - t0
+    dimA, dimB = trip.shape
+    csr, csc = api.coo_to_csr_csc(trip, use_float)   # host CSR / CSC (size_t indices) for the reference's ABI
+    A0, B0 = harness.initialize_matrices(dimA, dimB, K, use_float, 1)
+    times = []
+    for iters in (1, 2):
+        A, B = A0.copy(), B0.copy()
+        t0 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], l2, 0.0, 1.0, 1e-7, method, True, iters, maxupd,
+                           False, True, True, cores)
+        times.append(time.perf_counter() - t0)
+    dt = max(times[1] - times[0], 1e-9)
     nnz = len(csr[0])
     cpu = "unknown"
     try:
@@ -164,9 +206,10 @@ def cpu_baseline(csr, csc, dimA, dimB, method, use_float, maxupd):
                 break
     except OSError:
         pass
-    return {"value": nnz * sweeps / dt, "unit": "nnz/s per full sweep", "cores": int(cores), "kind": kind,
-            "sample": f"{sweeps} full A+B sweeps of the whole workload matrix ({nnz} nnz), method={method}, maxupd={maxupd}, "
-                      f"{'fp32' if use_float else 'fp64'}, OpenMP threads={cores} on {cpu}, {dt:.2f} s wall"}
+    return {"value": nnz / dt, "unit": "nnz/s per full sweep", "cores": int(cores), "kind": kind,
+            "sample": f"the whole workload matrix ({nnz} nnz), method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}: "
+                      f"run_poismf with 2 outer iterations ({times[1]:.2f} s) minus 1 outer iteration ({times[0]:.2f} s) = one steady-state "
+                      f"sweep, OpenMP threads={cores} on {cpu}"}
 
 
 def main():
@@ -177,20 +220,17 @@ def main():
     ap.add_argument("--method", default="pg")
     ap.add_argument("--maxupd", type=int, default=None)
     ap.add_argument("--fp64", action="store_true")
-    ap.add_argument("--k", type=int, default=None, help="factor dimension (default 50: the BASELINE configs)")
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--segments", type=int, default=None, help="segments of the A half (multi-GPU exchange / compute overlap)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     a = ap.parse_args()
-    global K
-    if a.k:
-        K = a.k
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     build.build()
@@ -201,95 +241,85 @@ def main():
         device = device % max(torch.cuda.device_count(), 1)
     backend = os.environ.get("POISMF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(device)
-    force_dist = os.environ.get("POISMF_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path on a single GPU (testing)
-    if world > 1 or force_dist:
+    if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if force_dist and "RANK" not in os.environ:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{device}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"))
         else:
-            if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"))
-            else:
-                dist.init_process_group(backend)
+            dist.init_process_group(backend)
 
+    dimA, dimB, ntrip = WORKLOADS[a.workload]
+    if os.environ.get("POISMF_BENCH_SCALE"):   # testing aid: the same shape shrunk by an integer factor
+        f = int(os.environ["POISMF_BENCH_SCALE"])
+        dimA, dimB, ntrip = dimA // f, dimB // f, ntrip // f
     use_float = not a.fp64
-    s = 4 if use_float else 8
-    csr, csc, dimA, dimB, rangesA, rangesB = build_inputs(rank, world, use_float)
-    res = run_gpu(csr, csc, dimA, dimB, rangesA, rangesB, rank, world, device, a.method, use_float, a.maxupd, a.steps, a.warmup)
+    t0 = time.perf_counter()
+    trip = synth.uniform_triplets(dimA, dimB, ntrip, seed=1)
+    gen_s = time.perf_counter() - t0
+    rangesA, rangesB = plan_ranges(trip, world)
+    segA = a.segments if a.segments is not None else (4 if world > 1 else 1)
+    job = Job(trip, rangesA, rangesB, rank, device, use_float, segA)
+    res = job.run(a.method, a.maxupd, a.steps, a.warmup)
+    prec = "f32" if use_float else "f64"
+    headline_roofline = roofline_block(job, res, f"{a.workload}_{a.method}_maxupd{res['maxupd']}_{prec}")
+    headline_setup_s = job.setup_s
 
     # whole-job totals
-    nnz_csr_local = res["nnz_local"][1]
-    tot = torch.tensor([float(nnz_csr_local), res["kernel_ms"][0][0], res["kernel_ms"][1][0]], dtype=torch.float64,
-                       device=f"cuda:{device}")
-    kmax = tot.clone()
+    tot = torch.tensor([float(job.nnz_local[1])], dtype=torch.float64, device=f"cuda:{device}")
     if dist.is_initialized():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     nnz_total = int(tot[0].item())
     final_line = None
+    single = world == 1
+    extra = {}
+    if single and not a.no_extra:
+        # the other points of the metric, same matrix, same session where the precision matches
+        for name, method, uf, mu, st, kw in (("pg_maxupd1_f32", "pg", True, 1, 10, {}),
+                                             ("pg_maxupd10_f32_finite", "pg", True, 10, 5, dict(l2=1e3, step0=1e-9)),
+                                             ("cg_f64", "cg", False, None, 3, {})):
+            if (name.startswith("pg") and a.method == "pg" and use_float and mu == res["maxupd"] and not kw):
+                continue
+            j2 = job
+            if uf != job.use_float:
+                job.close()
+                j2 = job = Job(trip, rangesA, rangesB, rank, device, uf, 1)
+            r = j2.run(method, mu, st, 1, **kw)
+            extra[name] = {"value": j2.nnz_local[1] * st / r["seconds"], "unit": "nnz/s", "ms_per_step": r["seconds"] / st * 1e3,
+                           "dtype": "f32" if uf else "f64", "method": method, "maxupd": r["maxupd"], "l2": r["l2"], "step": r["step0"],
+                           "steps": st, "finite": r["finite"],
+                           "roofline": roofline_block(j2, r, f"{a.workload}_{method}_maxupd{r['maxupd']}_{'f32' if uf else 'f64'}")}
     if rank == 0:
         sec = res["seconds"]
-        # roofline of the dominant kernel (half_sweep_kernel), this rank's launches: algorithmic bytes of the
-        # rank's two shards per sweep / its kernel time per sweep
-        b_half = [algorithmic_bytes_half(res["nnz_local"][0], rangesB[0][1] - rangesB[0][0], K, s),
-                  algorithmic_bytes_half(res["nnz_local"][1], rangesA[0][1] - rangesA[0][0], K, s)]
-        k_ms_sweep = (res["kernel_ms"][0][0] + res["kernel_ms"][1][0]) / a.steps
-        launches = res["kernel_ms"][0][1] + res["kernel_ms"][1][1]
-        achieved = sum(b_half) / (k_ms_sweep * 1e-3) / 1e9 if k_ms_sweep > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(f"{a.method}_maxupd{res['maxupd']}_{'f32' if use_float else 'f64'}")
-            except Exception:
-                traffic = None
         out = {
             "metric": "nonzeros/sec per full A+B sweep", "value": nnz_total * a.steps / sec, "unit": "nnz/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if use_float else "f64", "data": "synthetic",
-            "config": {"workload": f"uniform {dimA}x{dimB}, {nnz_total} nnz (1e7 triplets per 1e5-row block, duplicates summed), "
+            "config": {"workload": f"uniform {dimA}x{dimB}, {nnz_total} nnz ({ntrip} triplets, seed 1, duplicates summed), "
                                    f"k={K}, method={a.method}, maxupd={res['maxupd']}, l2={res['l2']:g}, step=1e-7",
-                       "baseline_config": "C2" if world == 1 else f"C2 x {world} row blocks (weak scaling towards C4)",
-                       "sharding": "none" if world == 1 else f"A rows and B rows split over {world} ranks, factors replicated, "
-                                                              "RCCL all-gather of the updated shard after each half"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "half_sweep_reg_kernel<float, pg, S> (register-tile row kernel; one launch per row-length bin, "
-                                   "S = 24/28/32/40 tile steps on this workload)",
-                         "kernel_ms_per_sweep": k_ms_sweep,
-                         "algorithmic_bytes_per_sweep": int(sum(b_half)), "half_sweeps_timed": int(launches),
-                         "note": "achieved = algorithmic bytes of one sweep's row-kernel launches / their summed duration (HIP events on "
-                                 "the session stream around each half's launches; serial launches, so this equals sum(Calls x AverageNs) "
-                                 "of the half_sweep_* rows of profiles/r01/kt_pg10_kernel_stats.csv); bytes = nnz*(4+s+k*s) + 2*dimM*k*s + "
-                                 "(dimM+1)*8 per half; traffic = fabric-side bytes per sweep from the PMC passes in profiles/r01/"},
+                       "baseline_config": {"C4": "C4 (= C3's matrix): the 1M x 100K, 100M-nnz matrix of the metric", "C2": "C2"}[a.workload]
+                                          if not os.environ.get("POISMF_BENCH_SCALE") else f"{a.workload} shrunk (testing)",
+                       "sharding": "none" if single else f"one fixed matrix: A rows {rangesA} and B rows {rangesB} over {world} ranks "
+                                                         f"(balanced nonzeros), factors replicated, updated rows sent to every peer after "
+                                                         f"each half, A half in {segA} segments overlapping exchange and compute",
+                       "setup_s": {"triplets": gen_s, "session_from_coo": headline_setup_s}},
+            "roofline": headline_roofline,
             "results_finite": res["finite"],
         }
-        out["roofline"]["pass_weighted"] = pass_weighted(res, (rangesA[0][1] - rangesA[0][0]) + (rangesB[0][1] - rangesB[0][0]), a.steps, K, s)
-        if world == 1 and not a.no_extra:
-            extra = {}
-            for name, method, uf, mu, st in (("pg_maxupd1_f32", "pg", True, 1, 10), ("cg_f64", "cg", False, None, 3)):
-                c2, cc2 = (csr, csc) if uf == use_float else harness.process_data(
-                    sp.coo_matrix(synth.uniform_coo(dimA, dimB, BLOCK_NNZ, seed=1)), uf)
-                r = run_gpu(c2, cc2, dimA, dimB, rangesA, rangesB, 0, 1, device, method, uf, mu, st, 2)
-                ss = 4 if uf else 8
-                bb = algorithmic_bytes_half(r["nnz_local"][0], dimB, K, ss) + algorithmic_bytes_half(r["nnz_local"][1], dimA, K, ss)
-                km = (r["kernel_ms"][0][0] + r["kernel_ms"][1][0]) / st
-                extra[name] = {"value": r["nnz_local"][1] * st / r["seconds"], "unit": "nnz/s", "ms_per_step": r["seconds"] / st * 1e3,
-                               "roofline_frac": bb / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms_per_sweep": km,
-                               "finite": r["finite"], "pass_weighted": pass_weighted(r, dimA + dimB, st, K, ss)}
+        if extra:
             out["extra"] = extra
-        if world == 1 and not a.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(csr, csc, dimA, dimB, a.method, use_float, a.maxupd)
-        final_line = json.dumps(out)
+        final_line = out
+    if single and not a.no_cpu and rank == 0:
+        job.close()
+        final_line["cpu_baseline"] = cpu_baseline(trip, a.method, use_float, a.maxupd)
+    else:
+        job.close()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
-        print(final_line, flush=True)  # the one JSON line, after RCCL has printed whatever it prints
+        print(json.dumps(final_line), flush=True)  # the one JSON line, after RCCL has printed whatever it prints
 
 
 if __name__ == "__main__":

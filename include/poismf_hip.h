@@ -128,8 +128,11 @@ typedef struct poismf_hip_session poismf_hip_session;
 /* Creates a session on HIP device `device`.  Xr* / Xc* are HOST CSR / CSC arrays of the WHOLE matrix
  * (size_t indices, as in run_poismf); only rows [rowA_begin,rowA_end) of the CSR and rows
  * [rowB_begin,rowB_end) of the CSC (= columns of X) are uploaded.  Pass 0,dimA / 0,dimB for a
- * single-GPU session.  `stream` is a hipStream_t passed as void* (NULL = the default stream); all
- * work of this session is enqueued on it.  Returns 0, or 1 when out of memory / no device. */
+ * single-GPU session.  `stream` is a hipStream_t passed as void*; all work of this session is enqueued on it.
+ * NULL does NOT mean the legacy default stream: the session then creates and owns a non-blocking stream of its
+ * own, which is not ordered against work the caller enqueues elsewhere -- a caller that touches the factors
+ * through the device pointers below must either pass its own stream here or order its work against
+ * poismf_hip_session_stream().  Returns 0, or 1 when out of memory / no device. */
 POISMF_HIP_API int poismf_hip_session_create(
     poismf_hip_session **out, int device, void *stream,
     const real_t *Xr, const sparse_ix *Xr_indptr, const sparse_ix *Xr_indices,
@@ -137,18 +140,33 @@ POISMF_HIP_API int poismf_hip_session_create(
     size_t dimA, size_t dimB, size_t k,
     size_t rowA_begin, size_t rowA_end, size_t rowB_begin, size_t rowB_end);
 
+/* The same session built from HOST COO triplets (what PoisMF._process_data holds, ref: poismf/__init__.py:404-414):
+ * both orientations are converted on the device (duplicates summed, indices sorted, section 1c) and stay there -- the
+ * CSR / CSC never exist in host memory.  Only triplets whose row lies in [rowA_begin,rowA_end) enter the CSR shard and
+ * only those whose column lies in [rowB_begin,rowB_end) the CSC shard.  Requires n < 2^32. */
+POISMF_HIP_API int poismf_hip_session_create_coo(
+    poismf_hip_session **out, int device, void *stream,
+    const sparse_ix *row, const sparse_ix *col, const real_t *val, size_t n,
+    size_t dimA, size_t dimB, size_t k,
+    size_t rowA_begin, size_t rowA_end, size_t rowB_begin, size_t rowB_end);
+
 POISMF_HIP_API void poismf_hip_session_destroy(poismf_hip_session *s);
+
+/* The stream this session enqueues its work on (the one given at creation, or the one it created), as void*. */
+POISMF_HIP_API void *poismf_hip_session_stream(poismf_hip_session *s);
 
 /* Device pointers to the session-owned, replicated factors: A is [dimA x k], B is [dimB x k],
  * row-major real_t (allocations carry 16 bytes of slack because rows are gathered in 16-byte
  * slots).  The caller may wrap them (e.g. as torch tensors) to run collectives on them.
  * For small k the session also keeps a line-padded copy of each factor for its gathers; a
  * session whose shard is the whole factor refreshes that copy from its own row kernels and
- * must be told about outside writes: call the getter again (or set_factors) after writing
- * through a pointer obtained earlier.  Sessions with partial shards re-derive the copy from
- * the compact factor before every half-sweep, so shard exchanges need no such call. */
+ * must be told about outside writes: call poismf_hip_session_factors_dirty(s, which) (which = 0: B was
+ * written, 1: A) after every write through a pointer obtained earlier (calling the getter again or
+ * set_factors has the same effect).  Sessions with partial shards re-derive the copy from the compact
+ * factor before every half-sweep in any case. */
 POISMF_HIP_API real_t *poismf_hip_session_A(poismf_hip_session *s);
 POISMF_HIP_API real_t *poismf_hip_session_B(poismf_hip_session *s);
+POISMF_HIP_API void poismf_hip_session_factors_dirty(poismf_hip_session *s, int which);
 
 /* Host <-> device copies of the full factors (synchronous with respect to the session stream). */
 POISMF_HIP_API int poismf_hip_session_set_factors(poismf_hip_session *s, const real_t *A_host, const real_t *B_host);
@@ -175,6 +193,24 @@ typedef struct poismf_hip_params {
 POISMF_HIP_API int poismf_hip_half_sweep(poismf_hip_session *s, int which, const poismf_hip_params *p,
                           real_t step_size, real_t cnst_div, size_t *n_unchanged);
 
+/* Segments (multi-GPU overlap of the shard exchange with compute).  set_segments cuts the
+ * session's shard of half `which` into `nseg` contiguous row ranges of equal row counts (rows begin + n j / nseg ..
+ * begin + n (j + 1) / nseg), each sorted and binned on its own, and returns the number of segments (< 0 on error);
+ * segment_rows reports a segment's global row range; half_sweep_segment runs ONE segment: segment 0 also computes the
+ * column sums and resets the early-stop counter, the call that passes n_unchanged (the last segment) reads it.  Running
+ * segments 0 .. nseg-1 in order is bit-identical to one poismf_hip_half_sweep (a row's arithmetic depends on its
+ * length class only).  The caller orders its exchange of segment j's rows after that call on the session stream. */
+POISMF_HIP_API int poismf_hip_session_set_segments(poismf_hip_session *s, int which, int nseg);
+POISMF_HIP_API int poismf_hip_session_segment_rows(poismf_hip_session *s, int which, int seg, size_t *row_begin, size_t *row_end);
+POISMF_HIP_API int poismf_hip_half_sweep_segment(poismf_hip_session *s, int which, const poismf_hip_params *p,
+                          real_t step_size, real_t cnst_div, int seg, size_t *n_unchanged);
+
+/* run_poismf's outer loop (ref: src/poismf.c:506-608: B half, PG step halving, A half, TNCG early stop, SIGINT
+ * handling and return codes 0 / 1 / 2 exactly as in section 1) on a session that already holds X and the starting
+ * factors; `p->step_size` is the initial step.  PoisMF.fit uses it with poismf_hip_session_create_coo so that the
+ * converted CSR / CSC never leave the device. */
+POISMF_HIP_API int poismf_hip_session_run(poismf_hip_session *s, const poismf_hip_params *p, size_t numiter, int handle_interrupt);
+
 /* Wall-clock (HIP events on the session stream) of the row-update kernels launched by half-sweeps
  * since profiling was switched on: total milliseconds and number of kernel launches, per half.
  * Synchronises the stream. */
@@ -192,6 +228,10 @@ POISMF_HIP_API int poismf_hip_session_eval_stats(poismf_hip_session *s, int whic
  * This runs both on n sample arguments on the current device and reports the largest distance in ulps and the number
  * of special arguments (+-0, -1, +-inf, NaN) on which they disagree.  Returns 0 on success. */
 POISMF_HIP_API int poismf_hip_selftest_log(size_t n, unsigned long long *worst_ulp, unsigned *mismatched_specials);
+
+/* Which row-kernel instances the most recent half-sweep of half `which` launched, as text ("kernel<instance> rows=N;"
+ * per launch), NUL-terminated and truncated to cap bytes; returns the untruncated length.  Reporting only. */
+POISMF_HIP_API size_t poismf_hip_session_plan(poismf_hip_session *s, int which, char *buf, size_t cap);
 
 /* Number of nonzeros held by this session for half `which` (shard only). */
 POISMF_HIP_API size_t poismf_hip_session_nnz(poismf_hip_session *s, int which);

@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_B", "poismf_hip_session_set_factors", "poismf_hip_session_get_factors",
     "poismf_hip_half_sweep", "poismf_hip_session_profile", "poismf_hip_session_kernel_time",
     "poismf_hip_session_nnz", "poismf_hip_selftest_log", "poismf_hip_session_eval_stats",
+    "poismf_hip_session_create_coo", "poismf_hip_session_stream", "poismf_hip_session_factors_dirty", "poismf_hip_session_run",
+    "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
 )
 
 
@@ -69,8 +71,14 @@ def load_library(use_float):
     lib.poismf_hip_coo_to_csr_csc.restype = i
     lib.poismf_hip_session_create.argtypes = [C.POINTER(vp), i, vp] + [vp] * 6 + [sz] * 3 + [sz] * 4
     lib.poismf_hip_session_create.restype = i
+    lib.poismf_hip_session_create_coo.argtypes = [C.POINTER(vp), i, vp, vp, vp, vp, sz] + [sz] * 3 + [sz] * 4
+    lib.poismf_hip_session_create_coo.restype = i
     lib.poismf_hip_session_destroy.argtypes = [vp]
     lib.poismf_hip_session_destroy.restype = None
+    lib.poismf_hip_session_stream.argtypes = [vp]
+    lib.poismf_hip_session_stream.restype = vp
+    lib.poismf_hip_session_factors_dirty.argtypes = [vp, i]
+    lib.poismf_hip_session_factors_dirty.restype = None
     for name in ("poismf_hip_session_A", "poismf_hip_session_B"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = vp
@@ -80,6 +88,16 @@ def load_library(use_float):
     lib.params_t = _params_type(r)
     lib.poismf_hip_half_sweep.argtypes = [vp, i, C.POINTER(lib.params_t), r, r, C.POINTER(sz)]
     lib.poismf_hip_half_sweep.restype = i
+    lib.poismf_hip_session_set_segments.argtypes = [vp, i, i]
+    lib.poismf_hip_session_set_segments.restype = i
+    lib.poismf_hip_session_segment_rows.argtypes = [vp, i, i, C.POINTER(sz), C.POINTER(sz)]
+    lib.poismf_hip_session_segment_rows.restype = i
+    lib.poismf_hip_half_sweep_segment.argtypes = [vp, i, C.POINTER(lib.params_t), r, r, i, C.POINTER(sz)]
+    lib.poismf_hip_half_sweep_segment.restype = i
+    lib.poismf_hip_session_plan.argtypes = [vp, i, C.c_char_p, sz]
+    lib.poismf_hip_session_plan.restype = sz
+    lib.poismf_hip_session_run.argtypes = [vp, C.POINTER(lib.params_t), sz, i]
+    lib.poismf_hip_session_run.restype = i
     lib.poismf_hip_session_profile.argtypes = [vp, i]
     lib.poismf_hip_session_profile.restype = None
     lib.poismf_hip_session_kernel_time.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(sz)]
@@ -135,6 +153,17 @@ def _run_poismf(Xr, Xr_indices, Xr_indptr, Xc, Xc_indices, Xc_indptr, A, B, meth
     return ret
 
 
+def _coo_arrays(coo, use_float):
+    """(row, col, val) of a COO-like object as C-contiguous size_t / size_t / real_t arrays (no copy when they already are;
+    non-negative int64 indices are reinterpreted in place)"""
+    def ix(a):
+        a = np.asarray(a)
+        if a.dtype == np.int64 and a.flags["C_CONTIGUOUS"]:
+            return a.view(np.uint64)
+        return np.ascontiguousarray(a, dtype=np.uint64)
+    return ix(coo.row), ix(coo.col), np.ascontiguousarray(coo.data, dtype=np.float32 if use_float else np.float64)
+
+
 def coo_to_csr_csc(coo, use_float):
     """GPU replacement of harness.process_data (ref: poismf/__init__.py:404-414): SciPy COO -> (csr, csc) tuples of
     (data real_t, indices size_t, indptr size_t) with duplicates summed and indices sorted."""
@@ -143,9 +172,7 @@ def coo_to_csr_csc(coo, use_float):
     n = coo.nnz
     if n == 0:
         raise ValueError("'X' contains no non-zero entries.")
-    row = np.ascontiguousarray(coo.row, dtype=np.uint64)
-    col = np.ascontiguousarray(coo.col, dtype=np.uint64)
-    val = np.ascontiguousarray(coo.data, dtype=dt)
+    row, col, val = _coo_arrays(coo, use_float)
     dimA, dimB = coo.shape
     cv, ci, cp = np.empty(n, dt), np.empty(n, np.uint64), np.empty(dimA + 1, np.uint64)
     kv, ki, kp = np.empty(n, dt), np.empty(n, np.uint64), np.empty(dimB + 1, np.uint64)
@@ -230,13 +257,30 @@ class PoisMF:
         self.is_fitted = False
 
     def fit(self, X):
-        # COO -> CSR + CSC on the device (bit-identical to the SciPy conversion of the reference's _process_data)
+        # COO -> CSR + CSC on the device (bit-identical to the SciPy conversion of the reference's _process_data);
+        # the converted matrix stays in HBM and the alternation runs on it in place (run_poismf's loop, same return
+        # codes and exceptions) -- nothing but the triplets goes up and nothing but the factors comes back
         import scipy.sparse as sp
-        csr, csc = coo_to_csr_csc(sp.coo_matrix(X), self.use_float)
         self.nusers, self.nitems = X.shape
         self.A, self.B = harness.initialize_matrices(self.nusers, self.nitems, self.k, self.use_float,
                                                      self.random_state)
-        self._fit(csr, csc)
+        sess = Session.from_coo(sp.coo_matrix(X), self.k, self.use_float)
+        try:
+            sess.set_factors(self.A, self.B)
+            p = sess.make_params(self.method, self.l2_reg_, self.l1_reg_, self.weight_mult, self.initial_step, self.limit_step,
+                                 self.maxupd_, self.early_stop, self.reuse_prev)
+            ret = sess.run(p, self.niter_, self.handle_interrupt)
+            A, B = sess.get_factors()
+            self.A[...] = A
+            self.B[...] = B
+        finally:
+            sess.close()
+        if ret == 1:
+            raise MemoryError("Could not allocate enough memory.")
+        elif ret == 2 and not self.handle_interrupt:
+            raise InterruptedError("Procedure was interrupted")
+        self.Bsum = self.B.sum(axis=0) + self.l1_reg_
+        self.Amean = self.A.mean(axis=0)
         self.is_fitted = True
         return self
 
@@ -284,23 +328,39 @@ class Session:
     """Device-resident half-sweeps (include/poismf_hip.h section 2).  X, A and B stay in HBM; each call
     runs one half of the alternation on this session's row shard."""
 
-    def __init__(self, csr, csc, dimA, dimB, k, use_float, device=0, stream=None, shardA=None, shardB=None):
+    def __init__(self, csr, csc, dimA, dimB, k, use_float, device=0, stream=None, shardA=None, shardB=None, _coo=None):
         self.lib = load_library(use_float)
         self.use_float = bool(use_float)
         self.dimA, self.dimB, self.k = int(dimA), int(dimB), int(k)
-        _check_arrays(use_float, (csr[0], csc[0]), (csr[1], csr[2], csc[1], csc[2]))
-        if len(csr[0]) == 0:
-            raise ValueError("'X' contains no non-zero entries.")
         self.shardA = tuple(shardA) if shardA is not None else (0, self.dimA)
         self.shardB = tuple(shardB) if shardB is not None else (0, self.dimB)
         h = C.c_void_p()
-        rc = self.lib.poismf_hip_session_create(
-            C.byref(h), int(device), C.c_void_p(stream or 0), _ptr(csr[0]), _ptr(csr[2]), _ptr(csr[1]),
-            _ptr(csc[0]), _ptr(csc[2]), _ptr(csc[1]), self.dimA, self.dimB, self.k,
-            self.shardA[0], self.shardA[1], self.shardB[0], self.shardB[1])
+        if _coo is not None:
+            row, col, val = _coo
+            rc = self.lib.poismf_hip_session_create_coo(
+                C.byref(h), int(device), C.c_void_p(stream or 0), _ptr(row), _ptr(col), _ptr(val), len(val),
+                self.dimA, self.dimB, self.k, self.shardA[0], self.shardA[1], self.shardB[0], self.shardB[1])
+        else:
+            _check_arrays(use_float, (csr[0], csc[0]), (csr[1], csr[2], csc[1], csc[2]))
+            if len(csr[0]) == 0:
+                raise ValueError("'X' contains no non-zero entries.")
+            rc = self.lib.poismf_hip_session_create(
+                C.byref(h), int(device), C.c_void_p(stream or 0), _ptr(csr[0]), _ptr(csr[2]), _ptr(csr[1]),
+                _ptr(csc[0]), _ptr(csc[2]), _ptr(csc[1]), self.dimA, self.dimB, self.k,
+                self.shardA[0], self.shardA[1], self.shardB[0], self.shardB[1])
         if rc != 0 or not h.value:
             raise MemoryError("poismf_hip_session_create failed (no usable HIP device or out of memory)")
         self.h = h
+
+    @classmethod
+    def from_coo(cls, coo, k, use_float, device=0, stream=None, shardA=None, shardB=None):
+        """Session whose CSR and CSC are built on the device from the triplets of a SciPy COO matrix (duplicates summed,
+        indices sorted: bit-identical to tocsr() / tocsc()); with shards, only the triplets of the shard's rows
+        (CSR) / columns (CSC) are kept."""
+        if coo.nnz == 0:
+            raise ValueError("'X' contains no non-zero entries.")
+        return cls(None, None, coo.shape[0], coo.shape[1], k, use_float, device, stream, shardA, shardB,
+                   _coo=_coo_arrays(coo, use_float))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -334,24 +394,63 @@ class Session:
         return self.lib.params_t(l2_reg, l1_reg, w_mult, step_size, _METHOD[method], int(limit_step), int(maxupd),
                                  int(early_stop), int(reuse_prev))
 
-    def half_sweep(self, which, params, step_size, cnst_div, want_unchanged=False):
+    def half_sweep(self, which, params, step_size, cnst_div, want_unchanged=False, seg=None):
+        """One half-sweep over the session's shard, or (seg = j) over its segment j only."""
         n = C.c_size_t(0)
-        rc = self.lib.poismf_hip_half_sweep(self.h, int(which), C.byref(params), step_size, cnst_div,
-                                            C.byref(n) if want_unchanged else None)
+        if seg is None:
+            rc = self.lib.poismf_hip_half_sweep(self.h, int(which), C.byref(params), step_size, cnst_div,
+                                                C.byref(n) if want_unchanged else None)
+        else:
+            rc = self.lib.poismf_hip_half_sweep_segment(self.h, int(which), C.byref(params), step_size, cnst_div, int(seg),
+                                                        C.byref(n) if want_unchanged else None)
         if rc:
             raise RuntimeError("poismf_hip_half_sweep failed")
         return n.value
 
+    def set_segments(self, which, nseg):
+        n = self.lib.poismf_hip_session_set_segments(self.h, int(which), int(nseg))
+        if n < 1:
+            raise RuntimeError("poismf_hip_session_set_segments failed")
+        return n
+
+    def segment_rows(self, which, seg):
+        b, e = C.c_size_t(0), C.c_size_t(0)
+        if self.lib.poismf_hip_session_segment_rows(self.h, int(which), int(seg), C.byref(b), C.byref(e)):
+            raise IndexError("no such segment")
+        return b.value, e.value
+
+    def real(self, v):
+        """v rounded to the session's real_t, as a Python float (run_poismf does its step / divisor arithmetic in
+        real_t, ref: src/poismf.c:511, :532)"""
+        return float(np.float32(v)) if self.use_float else float(v)
+
+    def cnst_div(self, l2_reg, step_size):
+        """The PG divisor 1 / (1 + 2 l2 step) evaluated as run_poismf evaluates it (ref: src/poismf.c:511): l2 and the
+        step are real_t, the expression is double, the result is stored as real_t."""
+        return self.real(1. / (1. + 2. * self.real(l2_reg) * self.real(step_size)))
+
     def sweep(self, params, step_size):
         """One full outer iteration with the reference's schedule (ref: src/poismf.c:506-608): B half, then
         (PG) halve the step, then A half.  Returns the step for the next iteration."""
-        l2 = float(params.l2_reg)
-        cnst_div = 1. / (1. + 2. * l2 * step_size)
+        step_size = self.real(step_size)
+        cnst_div = self.cnst_div(params.l2_reg, step_size)
         self.half_sweep(0, params, step_size, cnst_div)
         if params.method == _METHOD["pg"]:
-            step_size *= 0.5
+            step_size = self.real(step_size * 0.5)
         self.half_sweep(1, params, step_size, cnst_div)
         return step_size
+
+    def run(self, params, niter, handle_interrupt=True):
+        """run_poismf's whole loop on this session (return codes 0 / 1 / 2 as run_poismf)"""
+        return self.lib.poismf_hip_session_run(self.h, C.byref(params), int(niter), int(bool(handle_interrupt)))
+
+    def stream(self):
+        """the hipStream_t this session enqueues on, as an integer handle"""
+        return self.lib.poismf_hip_session_stream(self.h) or 0
+
+    def factors_dirty(self, which):
+        """tell the session that factor `which` (0: B, 1: A) was written through a device pointer obtained earlier"""
+        self.lib.poismf_hip_session_factors_dirty(self.h, int(which))
 
     def profile(self, enable=True):
         self.lib.poismf_hip_session_profile(self.h, int(enable))
@@ -371,3 +470,14 @@ class Session:
 
     def nnz(self, which):
         return self.lib.poismf_hip_session_nnz(self.h, int(which))
+
+    def plan(self, which):
+        """the launches of the most recent half-sweep of half `which`: [(kernel instance, rows), ...]"""
+        buf = C.create_string_buffer(8192)
+        self.lib.poismf_hip_session_plan(self.h, int(which), buf, len(buf))
+        out = []
+        for item in buf.value.decode().split(";"):
+            if item.strip():
+                name, rows = item.rsplit(" rows=", 1)
+                out.append((name.strip(), int(rows)))
+        return out

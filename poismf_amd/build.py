@@ -2,10 +2,12 @@
 
     python -m poismf_amd.build [--force] [-v]
 
-Six translation units per precision -- the host side, one per inner solver (the row kernels of PG, CG and TNCG are
-the bulk of the compile time; poismf_hip.hip is compiled once for each with -DPMF_TU=...), the rocPRIM-based COO
-conversion and the serving kernels -- are compiled to object files side by side and linked; only stale objects are
-rebuilt.  A full build takes ~2 minutes on 8 cores.
+Six translation units per precision -- the host side (poismf_hip_host.hip), one per inner solver (the row kernels of
+PG, CG and TNCG are the bulk of the compile time; poismf_hip.hip is compiled once for each with -DPMF_TU=...), the
+rocPRIM-based COO conversion and the serving kernels -- are compiled to object files side by side and linked.  Every object and
+library carries a `.stamp` with the digest of its command line and sources: an object is rebuilt exactly when that
+digest changes (a different POISMF_HIP_EXTRA_FLAGS rebuilds everything it reaches; file times play no part).  A full
+build takes ~2 minutes on 8 cores.
 """
 import fcntl
 import hashlib
@@ -16,11 +18,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "poismf_hip.h")
-_ROW = ["poismf_hip.hip", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "wave_ops.hpp"]
-# unit -> (source files, first is the one compiled; extra flags).  poismf_hip.hip is compiled four times: the host side
-# and one translation unit per inner solver (its row kernels are the bulk of the compile time).
+_ROW = ["poismf_hip.hip", "plan.hpp", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "wave_ops.hpp"]
+_HOST = ["poismf_hip_host.hip", "plan.hpp", "row_eval.hpp", "wave_ops.hpp"]
+# unit -> (source files, first is the one compiled; extra flags).  poismf_hip.hip is compiled three times: one
+# translation unit per inner solver (its row kernels are the bulk of the compile time); the host side is its own file.
 UNITS = {
-    "poismf_hip_host": (_ROW, ["-DPMF_TU=0"]),
+    "poismf_hip_host": (_HOST, []),
     "poismf_hip_tncg": (_ROW, ["-DPMF_TU=1"]),
     "poismf_hip_cg": (_ROW, ["-DPMF_TU=2"]),
     "poismf_hip_pg": (_ROW, ["-DPMF_TU=3"]),
@@ -37,8 +40,27 @@ def _obj_path(unit, use_float):
     return os.path.join(CSRC, f"{unit}_{'f' if use_float else 'd'}.o")
 
 
-def _stale(out, deps):
-    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+def _digest(parts, files):
+    """sha256 over strings and file contents"""
+    h = hashlib.sha256(repr(parts).encode())
+    for path in files:
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
+def _fresh(out, digest):
+    """`out` exists and was produced from exactly the inputs `digest` stands for (sources AND flags: a changed
+    POISMF_HIP_EXTRA_FLAGS rebuilds, file times play no part)"""
+    try:
+        return os.path.exists(out) and open(out + ".stamp").read().strip() == digest
+    except OSError:
+        return False
+
+
+def _mark(out, digest):
+    with open(out + ".stamp", "w") as fh:
+        fh.write(digest + "\n")
 
 
 STAMP = os.path.join(HERE, ".build_stamp")   # hash of the sources + flags the in-tree libraries were built from
@@ -47,7 +69,8 @@ STAMP = os.path.join(HERE, ".build_stamp")   # hash of the sources + flags the i
 def _units():
     """The -DPMF_TIMING development build keeps its phase timers in one device-side array, so it stays one translation unit."""
     if "-DPMF_TIMING" in os.environ.get("POISMF_HIP_EXTRA_FLAGS", "").split():
-        return {"poismf_hip_all": (_ROW, []), "coo_convert": UNITS["coo_convert"], "serve": UNITS["serve"]}
+        return {"poismf_hip_host": UNITS["poismf_hip_host"], "poismf_hip_all": (_ROW, []), "coo_convert": UNITS["coo_convert"],
+                "serve": UNITS["serve"]}
     return UNITS
 
 
@@ -58,12 +81,8 @@ def _flags():
 
 
 def _source_hash():
-    h = hashlib.sha256((" ".join(_flags()) + repr(sorted((u, f) for u, (_, f) in _units().items()))).encode())
     names = sorted({f for files, _ in _units().values() for f in files})
-    for path in [os.path.join(CSRC, f) for f in names] + [HEADER]:
-        with open(path, "rb") as fh:
-            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
-    return h.hexdigest()
+    return _digest([_flags(), sorted((u, f) for u, (_, f) in _units().items())], [os.path.join(CSRC, f) for f in names] + [HEADER])
 
 
 def up_to_date():
@@ -95,26 +114,37 @@ def _build_locked(force, verbose):
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     compiles = []
+    digests = {}
     for use_float in (False, True):
         for unit, (files, unit_flags) in _units().items():
             deps = [os.path.join(CSRC, f) for f in files] + [HEADER]
             obj = _obj_path(unit, use_float)
-            if force or _stale(obj, deps):
-                cmd = [hipcc] + (["-DUSE_FLOAT"] if use_float else []) + flags + unit_flags + ["-c", os.path.join(CSRC, files[0]), "-o", obj]
+            cmd = [hipcc] + (["-DUSE_FLOAT"] if use_float else []) + flags + unit_flags + ["-c", os.path.join(CSRC, files[0]), "-o", obj]
+            digests[obj] = _digest(cmd, deps)
+            if force or not _fresh(obj, digests[obj]):
                 if verbose:
                     print(" ".join(cmd))
-                compiles.append((cmd, subprocess.Popen(cmd)))   # all stale objects compile side by side
-    for cmd, p in compiles:
+                if os.path.exists(obj + ".stamp"):
+                    os.remove(obj + ".stamp")
+                compiles.append((cmd, obj, subprocess.Popen(cmd)))   # all stale objects compile side by side
+    failed = None
+    for cmd, obj, p in compiles:
         if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+            failed = failed or subprocess.CalledProcessError(p.returncode, cmd)
+        else:
+            _mark(obj, digests[obj])
+    if failed:
+        raise failed
     for use_float in (False, True):
         out = lib_path(use_float)
         objs = [_obj_path(u, use_float) for u in _units()]
-        if force or _stale(out, objs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        digest = _digest(cmd + [digests[o] for o in objs], [])
+        if force or not _fresh(out, digest):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            _mark(out, digest)
     return lib_path(False), lib_path(True)
 
 

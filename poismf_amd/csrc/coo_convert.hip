@@ -32,10 +32,25 @@ namespace {
         }                                                                                          \
     } while (0)
 
-__global__ void pack_keys(const unsigned* major, const unsigned* minor, size_t n, unsigned long long* keys)
+// Triplets whose major index lies outside [m0, m1) get the all-ones key: they sort behind every real key, collapse
+// into one trailing entry in the reduction and are dropped there (row shards of the multi-GPU driver).
+__global__ void pack_keys(const unsigned* major, const unsigned* minor, size_t n, unsigned m0, unsigned m1, unsigned long long* keys)
 {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        keys[i] = ((unsigned long long)major[i] << 32) | (unsigned long long)minor[i];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned m = major[i];
+        keys[i] = (m >= m0 && m < m1) ? (((unsigned long long)(m - m0) << 32) | (unsigned long long)minor[i]) : ~0ull;
+    }
+}
+__global__ void row_len_kernel(const unsigned long long* indptr, size_t n, unsigned base, unsigned* len, unsigned* ids)
+{
+    for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < n; r += (size_t)gridDim.x * blockDim.x) {
+        len[r] = (unsigned)(indptr[r + 1] - indptr[r]);
+        ids[r] = base + (unsigned)r;
+    }
+}
+__global__ void narrow_kernel(const unsigned long long* src, size_t n, unsigned* dst)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (unsigned)src[i];
 }
 __global__ void split_keys(const unsigned long long* keys, size_t n, unsigned* minor)
 {
@@ -65,13 +80,15 @@ int bits_for(size_t v)
 
 }  // namespace
 
-// One orientation, everything on the device.  d_major / d_minor / d_val: n triplets.  Outputs (device, capacity n):
-// out_minor (u32), out_val, out_indptr (dim_major + 1, u64); *nnz_out = number of distinct (major, minor) pairs.
-// Scratch is allocated and freed inside.  Exported for poismf_hip.hip (session creation from COO).
-int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor, const real_t* d_val, size_t n, size_t dim_major,
-                                size_t dim_minor, unsigned* out_minor, real_t* out_val, unsigned long long* out_indptr,
+// One orientation, everything on the device.  d_major / d_minor / d_val: n triplets, of which those with major index in
+// [major_begin, major_end) are kept (rebased to major_begin).  Outputs (device, capacity n): out_minor (u32), out_val,
+// out_indptr (major_end - major_begin + 1, u64); *nnz_out = number of distinct (major, minor) pairs kept.
+// Scratch is allocated and freed inside.  Also called by poismf_hip.hip (session creation from COO).
+int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor, const real_t* d_val, size_t n, size_t major_begin,
+                                size_t major_end, unsigned* out_minor, real_t* out_val, unsigned long long* out_indptr,
                                 size_t* nnz_out, hipStream_t stream)
 {
+    const size_t dim_major = major_end - major_begin;
     unsigned long long *keys_a = nullptr, *keys_b = nullptr;
     real_t* vals_b = nullptr;
     size_t* d_count = nullptr;
@@ -89,11 +106,11 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
     TRY_OR_CLEAN(hipMalloc(&vals_b, sizeof(real_t) * n));
     TRY_OR_CLEAN(hipMalloc(&d_count, sizeof(size_t)));
     const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(pack_keys, dim3(grid), dim3(256), 0, stream, d_major, d_minor, n, keys_a);
+    hipLaunchKernelGGL(pack_keys, dim3(grid), dim3(256), 0, stream, d_major, d_minor, n, (unsigned)major_begin, (unsigned)major_end, keys_a);
 
-    // stable LSD radix sort on the significant bits only: minor in [0, 32), major above
-    const unsigned end_bit = (unsigned)(32 + bits_for(dim_major));
-    (void)dim_minor;
+    // stable LSD radix sort on the significant bits only: minor in [0, 32), major above (the all-ones key of dropped
+    // triplets is all ones in those bits too, and no real key is: minor indices stay below 2^31)
+    const unsigned end_bit = (unsigned)(32 + bits_for(dim_major + 1));
     size_t tmp_bytes = 0;
     TRY_OR_CLEAN(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, d_val, vals_b, n, 0u, end_bit, stream));
     TRY_OR_CLEAN(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
@@ -110,6 +127,12 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
     size_t uniq = 0;
     TRY_OR_CLEAN(hipMemcpyAsync(&uniq, d_count, sizeof(size_t), hipMemcpyDeviceToHost, stream));
     TRY_OR_CLEAN(hipStreamSynchronize(stream));
+    if (uniq > 0) {   // the trailing entry of the dropped triplets, if any
+        unsigned long long last = 0;
+        TRY_OR_CLEAN(hipMemcpyAsync(&last, keys_a + (uniq - 1), sizeof(last), hipMemcpyDeviceToHost, stream));
+        TRY_OR_CLEAN(hipStreamSynchronize(stream));
+        if (last == ~0ull) uniq--;
+    }
     const unsigned g2 = (unsigned)std::min<size_t>((uniq + 255) / 256 + 1, 256 * 8);
     hipLaunchKernelGGL(split_keys, dim3(g2), dim3(256), 0, stream, keys_a, uniq, out_minor);
     const unsigned g3 = (unsigned)std::min<size_t>((dim_major + 256) / 256, 256 * 8);
@@ -120,6 +143,41 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
     cleanup();
 #undef TRY_OR_CLEAN
     return 0;
+}
+
+// nloc consecutive rows (d_indptr points at the first one's CSR pointer; its row id is `base`) sorted by length,
+// longest first, equal lengths in row order: d_perm[i] = row id, d_len_sorted[i] = its length.  (Stable LSD radix
+// sort of (length, row) pairs, descending.)
+int poismf_hip_device_sort_rows(const unsigned long long* d_indptr, size_t nloc, unsigned base, unsigned* d_perm, unsigned* d_len_sorted,
+                                hipStream_t stream)
+{
+    if (nloc == 0) return 0;
+    unsigned *len = nullptr, *ids = nullptr;
+    void* tmp = nullptr;
+    auto cleanup = [&]() {
+        if (len) (void)hipFree(len);
+        if (ids) (void)hipFree(ids);
+        if (tmp) (void)hipFree(tmp);
+    };
+    if (hipMalloc(&len, sizeof(unsigned) * nloc) != hipSuccess || hipMalloc(&ids, sizeof(unsigned) * nloc) != hipSuccess) { cleanup(); return 1; }
+    const unsigned grid = (unsigned)std::min<size_t>((nloc + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(row_len_kernel, dim3(grid), dim3(256), 0, stream, d_indptr, nloc, base, len, ids);
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs_desc(nullptr, bytes, len, d_len_sorted, ids, d_perm, nloc, 0u, 32u, stream) != hipSuccess ||
+        hipMalloc(&tmp, bytes ? bytes : 16) != hipSuccess ||
+        rocprim::radix_sort_pairs_desc(tmp, bytes, len, d_len_sorted, ids, d_perm, nloc, 0u, 32u, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) { cleanup(); return 1; }
+    cleanup();
+    return 0;
+}
+
+// dst[i] = (u32) src[i] on the device (host CSR indices arrive as size_t)
+int poismf_hip_device_narrow(const unsigned long long* d_src, size_t n, unsigned* d_dst, hipStream_t stream)
+{
+    if (n == 0) return 0;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid), dim3(256), 0, stream, d_src, n, d_dst);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 extern "C" {
@@ -154,7 +212,7 @@ int poismf_hip_coo_to_csr_csc(const sparse_ix* row, const sparse_ix* col, const 
         for (int pass = 0; pass < 2 && ok; pass++) {
             const bool csr = pass == 0;
             size_t uniq = 0;
-            if (poismf_hip_device_coo_to_cs(csr ? d_row : d_col, csr ? d_col : d_row, d_val, n, csr ? dimA : dimB, csr ? dimB : dimA,
+            if (poismf_hip_device_coo_to_cs(csr ? d_row : d_col, csr ? d_col : d_row, d_val, n, 0, csr ? dimA : dimB,
                                             d_minor, d_oval, d_ptr, &uniq, stream)) { ok = false; break; }
             const size_t dim = csr ? dimA : dimB;
             real_t* oval = csr ? csr_val : csc_val;

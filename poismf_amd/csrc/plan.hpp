@@ -1,0 +1,142 @@
+// plan.hpp -- what the host side (poismf_hip_host.hip) and the row-kernel translation units (poismf_hip.hip, compiled once
+// per inner solver) share: the kernel argument block, the description of one planned launch, and the constants / small
+// functions that decide which engine and which instance a row-length bin takes.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+
+#include "../../include/poismf_hip.h"
+#include "row_eval.hpp"
+
+using namespace pmf;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "poismf_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));          \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+struct RowDesc;
+template <class T> struct HalfArgs {
+    T* M;                             // factor being updated, [dimM x k]
+    T* Mp;                            // its line-padded copy (row stride ldM), or nullptr: updated rows go to both
+    int ldM;
+    const T* F;                       // opposing factor, [dimF x k] (+16 B of slack)
+    const unsigned long long* indptr; // shard-local CSR row pointers (nrows_local + 1)
+    const unsigned* indices;
+    const T* values;
+    const unsigned* perm;             // shard-local row ids, sorted by nnz descending
+    const struct RowDesc* desc;       // the same order, with each row's CSR offset and length (one load per row)
+    unsigned perm_begin, nrows;       // this launch covers perm[perm_begin, perm_begin + nrows)
+    unsigned row_offset;              // first global row of the shard (M row = row_offset + local id)
+    const T* bsum;                    // k-vector: colsum(F) + l1 (pre-scaled for PG when w == 1)
+    TileGeom geom;
+    RowParams<T> P;
+    int reuse_prev, early_stop;
+    unsigned* n_unchanged;
+    unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
+    unsigned* eval_rows;              // != nullptr (profiling sessions): [local row] += passes over that row's tile
+};
+
+enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
+
+// One row of the sorted order: where its nonzeros start in the shard's CSR arrays, how many, and which row it is.
+struct RowDesc { unsigned p0_lo, p0_hi, nnz, lrow; };
+
+namespace {
+
+constexpr size_t LDS_PER_CU = 160 * 1024;
+
+// Slot counts with a compile-time specialisation: the k values of the BASELINE configs
+// (fp32: k = 49..52 -> 13 slots, k = 97..100 -> 25; fp64: k = 49..50 -> 25, k = 99..100 -> 50).
+#ifdef USE_FLOAT
+constexpr int SPECIAL_SL_A = 13, SPECIAL_SL_B = 25;
+#else
+constexpr int SPECIAL_SL_A = 25, SPECIAL_SL_B = 50;
+#endif
+
+// ---- register-tile engine (reg_eval.hpp) ---------------------------------------------------------------------------
+// A factor row is held by REG_G lanes (NS = 1 or 2 slots per lane); a step covers 64 / REG_G nonzeros.  Tile steps S
+// with an instantiated kernel; a bin takes the smallest S that covers its longest row.
+#ifndef PMF_REG_G
+#define PMF_REG_G 16
+#endif
+constexpr int REG_G = PMF_REG_G;
+constexpr int REG_JG = WAVE / REG_G;
+// tile sizes in nonzeros with an instantiated kernel (S = nonzeros / REG_JG steps)
+#define PMF_REG_SIZES(X) X(16) X(32) X(48) X(64) X(80) X(96) X(112) X(128) X(144) X(160)
+constexpr int REG_NNZ_MAX = 160;
+int reg_steps_for(unsigned max_nnz)
+{
+#define X(NZ) if ((unsigned)(NZ) >= max_nnz) return (NZ) / REG_JG;
+    PMF_REG_SIZES(X)
+#undef X
+    return 0;
+}
+
+// longest row (nonzeros) each solver runs from a register tile; beyond it the LDS engine has more waves per CU
+#ifndef PMF_REG_MAX_CG
+#define PMF_REG_MAX_CG 160
+#endif
+#ifndef PMF_REG_MAX_TNCG
+#define PMF_REG_MAX_TNCG 160
+#endif
+constexpr int REG_NNZ_MAX_CG = PMF_REG_MAX_CG, REG_NNZ_MAX_TNCG = PMF_REG_MAX_TNCG;
+unsigned reg_nnz_max(int method) { return method == POISMF_PG ? REG_NNZ_MAX : method == POISMF_CG ? REG_NNZ_MAX_CG : REG_NNZ_MAX_TNCG; }
+
+constexpr int REG_NW_MAX = 8;   // the same engine with 2, 4 or 8 wavefronts per row
+// Several waves per row: the longest share of a row one wave keeps in registers, per solver (CG / TNCG carry more state)
+constexpr int REGW_WAVE_NNZ_MAX_PG = 160, REGW_WAVE_NNZ_MAX_CG = 128, REGW_WAVE_NNZ_MAX_TNCG = 96;
+unsigned regw_wave_nnz_max(int method)
+{
+    return (unsigned)(method == POISMF_PG ? REGW_WAVE_NNZ_MAX_PG : method == POISMF_CG ? REGW_WAVE_NNZ_MAX_CG : REGW_WAVE_NNZ_MAX_TNCG);
+}
+unsigned regw_nnz_max(int method) { return (unsigned)REG_NW_MAX * regw_wave_nnz_max(method); }
+// the fewest waves (2, 4, 8) whose shares of a row of max_nnz nonzeros fit
+int regw_waves_for(unsigned max_nnz, int method)
+{
+    for (int nw : { 2, 4, 8 })
+        if (max_nnz <= (unsigned)nw * regw_wave_nnz_max(method)) return nw;
+    return 0;
+}
+// tile steps for a row of max_nnz nonzeros split over nw waves (each wave's share is rounded up to whole steps)
+int regw_steps_for(unsigned max_nnz, int nw)
+{
+    const unsigned share = ((max_nnz + (unsigned)nw - 1) / (unsigned)nw + REG_JG - 1) / REG_JG * REG_JG;
+    return reg_steps_for(std::max(32u, share));
+}
+
+// Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
+constexpr unsigned LONG_ROW_NNZ = 8192;
+constexpr int LONG_NW = 8;
+constexpr int SLOT_ELEMS = (int)(16 / sizeof(real_t));   // elements per 16-byte slot
+
+// row kernels: 16-byte slots per lane (slot layout of row_eval.hpp); 0 = unsupported
+int slots_per_lane(size_t k)
+{
+    const size_t s_load = (k * sizeof(real_t) + 15) / 16;
+    return s_load <= 64 ? 1 : (s_load <= 128 ? 2 : 0);
+}
+
+}  // namespace
+
+// One row-bin launch: everything the planner decided, minus the solver (which selects the translation unit).
+struct OneLaunch {
+    int reg_S, nw, s_load, spl;   // register-engine steps (0: LDS engine), waves per row, slots per factor row, slots per lane
+    bool generic_only;
+    hipStream_t main_stream, bin_stream, long_stream;
+    size_t lds;
+    unsigned grid, grid_mult;
+    int device, num_cu;
+};
+
+
+// One function per row-kernel translation unit (PMF_TU = 1 tncg, 2 cg, 3 pg): launches the instance the plan names.
+int pmf_launch_one_tu1(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
+int pmf_launch_one_tu2(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
+int pmf_launch_one_tu3(int method, const OneLaunch& o, const HalfArgs<real_t>& a);

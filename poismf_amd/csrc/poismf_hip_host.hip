@@ -1,0 +1,1157 @@
+// poismf_hip_host.hip -- host side of the MI355X implementation of poismf's alternating factor-update path: the outer
+// A/B alternation, step schedule, early-stop logic, SIGINT plumbing and return codes of run_poismf
+// (ref: src/poismf.c:435-632), the device-resident session used by bench.py and by the one-process-per-GPU driver,
+// the planning of a half-sweep into row-bin launches, and the small dense kernels (column sums, padded copies).
+// The row kernels are poismf_hip.hip (one translation unit per inner solver); the C-ABI is include/poismf_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <csignal>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "plan.hpp"
+
+static int launch_one(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
+{
+    return method == POISMF_PG ? pmf_launch_one_tu3(method, o, a) : method == POISMF_CG ? pmf_launch_one_tu2(method, o, a) : pmf_launch_one_tu1(method, o, a);
+}
+
+#define PMF_EW _Pragma("unroll") for (int i = 0; i < NC; i++)
+
+// ---- self-test of wave_ops.hpp's d_log against the device library's log --------------------------------------------
+__global__ __launch_bounds__(256) void selftest_log_kernel(unsigned long long n, unsigned long long* worst_ulp, unsigned* mismatched_specials)
+{
+    unsigned long long worst = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        // arguments: a dense sweep of [1/4, 4] (where cancellation is worst), then 2^-1074 .. 2^1023 through bit patterns
+        double x;
+        if (i < n / 2) x = 0.25 + 3.75 * (double)i / (double)(n / 2);
+        else {
+            const unsigned long long j = i - n / 2, m = n - n / 2;
+            const unsigned long long bits = (unsigned long long)((double)j / (double)m * (double)0x7fefffffffffffffULL);
+            x = __builtin_bit_cast(double, bits ? bits : 1ULL);
+        }
+        const double a = d_log(x), b = d_log_lib(x);
+        const long long ia = __builtin_bit_cast(long long, a), ib = __builtin_bit_cast(long long, b);
+        const unsigned long long d = (unsigned long long)(ia > ib ? ia - ib : ib - ia);   // same sign: distance in ulps
+        if ((ia < 0) == (ib < 0)) worst = d > worst ? d : worst;
+        else if (a != b) worst = ~0ULL >> 1;
+    }
+    atomicMax(worst_ulp, worst);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double sp[6] = { 0.0, -0.0, -1.0, __builtin_inf(), -__builtin_inf(), __builtin_nan("") };
+        unsigned bad = 0;
+        for (int q = 0; q < 6; q++) {
+            const double a = d_log(sp[q]), b = d_log_lib(sp[q]);
+            const bool same = (a != a && b != b) || a == b;
+            bad += same ? 0u : 1u;
+        }
+        *mismatched_specials = bad;
+    }
+}
+
+
+// ---- compact factor -> line-padded copy (the pad columns stay zero from the allocation) --------------------------
+template <class T> __global__ __launch_bounds__(256) void repad_kernel(const T* src, T* dst, size_t n, int k, int ld)
+{
+    const size_t total = n * (size_t)k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (size_t)k;
+        const int c = (int)(i - r * (size_t)k);
+        dst[r * (size_t)ld + c] = src[i];
+    }
+}
+
+// ---- column sums of a dense [n x k] factor: sum_by_cols, ref: src/poismf.c:77-83 ---------------------
+// stage 1: wave w accumulates rows w, w + nw, ...; stage 2: one wave adds the nw partials in order,
+// then applies `+ l1` (ref: :513-514) and the PG pre-scalings (ref: :523-526, :573-577, quirk Q1).
+// stage 1: blocks of 8 waves; wave w of block b accumulates rows (b*8 + w), + 8*grid, ...; the 8 wave totals are added
+// through LDS in wave order, so the 256-way partial written by the block is bit-reproducible.
+constexpr int COLSUM_BLOCK_WAVES = 8;
+template <class T, int NC>
+__global__ __launch_bounds__(WAVE* COLSUM_BLOCK_WAVES) void colsum_partial_kernel(const T* M, size_t n, int k, T* partial)
+{
+    __shared__ T part[COLSUM_BLOCK_WAVES][NC * WAVE];
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x / WAVE);
+    T acc[NC];
+    PMF_EW acc[i] = (T)0;
+    // four rows in flight per wave (the loop is latency-bound: one 200-byte row per trip); added in row order as before
+    const size_t stride = (size_t)gridDim.x * COLSUM_BLOCK_WAVES;
+    size_t r = (size_t)blockIdx.x * COLSUM_BLOCK_WAVES + w;
+    for (; r + 3 * stride < n; r += 4 * stride) {
+        T v[4][NC];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const T* row = M + (r + u * stride) * (size_t)k;
+            PMF_EW v[u][i] = (lane + WAVE * i < k) ? row[lane + WAVE * i] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { PMF_EW acc[i] += v[u][i]; }
+    }
+    for (; r < n; r += stride) {
+        const T* row = M + r * (size_t)k;
+        PMF_EW if (lane + WAVE * i < k) acc[i] += row[lane + WAVE * i];
+    }
+    PMF_EW part[w][lane + WAVE * i] = acc[i];
+    __syncthreads();
+    if (w == 0) {
+        PMF_EW {
+            const int c = lane + WAVE * i;
+            if (c < k) {
+                T s = part[0][c];
+                for (int q = 1; q < COLSUM_BLOCK_WAVES; q++) s += part[q][c];
+                partial[(size_t)blockIdx.x * k + c] = s;
+            }
+        }
+    }
+}
+// stage 2: 16 waves; wave w adds partials w, w + 16, ... in order, then wave 0 adds the 16 wave totals in order
+// (fixed summation order => bit-reproducible), applies `+ l1` and the PG pre-scalings.
+constexpr int COLSUM_FINAL_WAVES = 16;
+template <class T, int NC>
+__global__ __launch_bounds__(WAVE* COLSUM_FINAL_WAVES) void colsum_final_kernel(const T* partial, int nw, int k, T l1, T scale,
+                                                                                 int nscale, T* out)
+{
+    __shared__ T part[COLSUM_FINAL_WAVES][NC * WAVE];
+    const int lane = lane_id();
+    const int w = (int)(threadIdx.x / WAVE);
+    T acc[NC];
+    PMF_EW acc[i] = (T)0;
+    int r = w;
+    for (; r + 7 * COLSUM_FINAL_WAVES < nw; r += 8 * COLSUM_FINAL_WAVES) {   // eight loads in flight, same order of adds
+        T v[8][NC];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            PMF_EW v[u][i] = (lane + WAVE * i < k) ? partial[(size_t)(r + u * COLSUM_FINAL_WAVES) * k + lane + WAVE * i] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { PMF_EW acc[i] += v[u][i]; }
+    }
+    for (; r < nw; r += COLSUM_FINAL_WAVES) {
+        PMF_EW if (lane + WAVE * i < k) acc[i] += partial[(size_t)r * k + lane + WAVE * i];
+    }
+    PMF_EW part[w][lane + WAVE * i] = acc[i];
+    __syncthreads();
+    if (w == 0) {
+        PMF_EW {
+            const int c = lane + WAVE * i;
+            if (c < k) {
+                T s = part[0][c];
+                for (int q = 1; q < COLSUM_FINAL_WAVES; q++) s += part[q][c];
+                if (l1 > (T)0.) s += l1;
+                for (int q = 0; q < nscale; q++) s *= scale;
+                out[c] = s;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// Host side
+// =================================================================================================
+// coo_convert.hip (rocPRIM-based helpers)
+int poismf_hip_device_sort_rows(const unsigned long long* d_indptr, size_t nloc, unsigned base, unsigned* d_perm, unsigned* d_len_sorted,
+                                hipStream_t stream);
+int poismf_hip_device_narrow(const unsigned long long* d_src, size_t n, unsigned* d_dst, hipStream_t stream);
+int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor, const real_t* d_val, size_t n, size_t major_begin,
+                                size_t major_end, unsigned* out_minor, real_t* out_val, unsigned long long* out_indptr,
+                                size_t* nnz_out, hipStream_t stream);
+
+namespace {
+
+constexpr size_t LDS_RESIDENT_LIMIT = 64 * 1024;  // largest tile a single wave may claim
+constexpr int MAX_LAUNCHES = 64;  // row bins per half-sweep (16 fine classes + powers of two up to 2^31)
+
+struct Bin {
+    unsigned begin, count;  // range of the nnz-sorted permutation
+    unsigned max_nnz;       // longest row actually in the bin (sizes tiles)
+    unsigned cls;           // upper bound of the bin's length class (decides the code path: a function of the row alone)
+};
+
+struct Half {
+    size_t dimM = 0, dimF = 0;
+    size_t row_begin = 0, row_end = 0;  // shard
+    size_t nnz = 0;
+    unsigned long long* d_indptr = nullptr;
+    unsigned* d_indices = nullptr;
+    real_t* d_values = nullptr;
+    unsigned* d_perm = nullptr;
+    RowDesc* d_desc = nullptr;
+    unsigned* d_eval_rows = nullptr;      // per local row: passes over its tile while profiling (allocated on demand)
+    // The shard's rows are cut into contiguous SEGMENTS (one unless the multi-GPU driver asks for more, so that a
+    // segment's rows can travel while the next one computes); within a segment rows are sorted by length and binned.
+    struct Segment { unsigned row_lo, row_hi; std::vector<Bin> bins; };
+    std::vector<Segment> segs;
+};
+
+struct ProfRec { hipEvent_t t0, t1; int which; };
+
+}  // namespace
+
+struct poismf_hip_session {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    hipStream_t aux_stream = nullptr;  // long-row launches run here, next to the other bins
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    size_t dimA = 0, dimB = 0, k = 0;
+    real_t *dA = nullptr, *dB = nullptr;
+    // line-padded copies of the factors for the gathers (row stride `ld` elements = a multiple of 128 bytes), kept when
+    // that cuts the bytes a gathered row drags in by >= 10 %; refreshed from the compact factor before each half-sweep
+    real_t *dAp = nullptr, *dBp = nullptr;
+    size_t ld = 0;
+    bool padded_fresh[2] = { false, false };  // [0]: dBp mirrors dB, [1]: dAp mirrors dA
+    Half half[2];  // [0]: rows of B (CSC), [1]: rows of A (CSR)
+    real_t* d_bsum = nullptr;
+    real_t* d_partial = nullptr;
+    unsigned* d_counter = nullptr;
+    unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
+    int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::string last_plan[2];         // the launches of the most recent half-sweep of each half, as text
+};
+
+namespace {
+
+void free_half(Half& h)
+{
+    if (h.d_indptr) (void)hipFree(h.d_indptr);
+    if (h.d_indices) (void)hipFree(h.d_indices);
+    if (h.d_values) (void)hipFree(h.d_values);
+    if (h.d_perm) (void)hipFree(h.d_perm);
+    if (h.d_desc) (void)hipFree(h.d_desc);
+    if (h.d_eval_rows) (void)hipFree(h.d_eval_rows);
+    h = Half();
+}
+
+// ---- device-side set-up of one half ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void rebase_indptr_kernel(unsigned long long* indptr, size_t n, unsigned long long base)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) indptr[i] -= base;
+}
+__global__ __launch_bounds__(256) void row_desc_kernel(const unsigned long long* indptr, const unsigned* perm, size_t n, RowDesc* desc)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned r = perm[i];
+        const unsigned long long p0 = indptr[r];
+        desc[i] = { (unsigned)p0, (unsigned)(p0 >> 32), (unsigned)(indptr[r + 1] - p0), r };
+    }
+}
+
+// bin classes: multiples of 16 up to 256 nonzeros, multiples of 64 up to 1280 (the hand-overs between 1, 2, 4
+// and 8 waves per row fall on those), then powers of two.  The LDS tile of a launch is sized by the longest
+// row of its bin, and LDS is what limits the waves per CU, so fine classes where most rows live buy
+// occupancy (C2: 100 +- 10 nnz per row -> 7 waves per CU instead of 5).  Which ENGINE a row takes, and how
+// many waves share it, is decided by the class bound alone -- never by which other rows happen to be in the
+// shard -- so a row's arithmetic does not depend on how the matrix is cut into shards.
+unsigned length_class(unsigned n)
+{
+    if (n <= 256) return std::max(16u, (n + 15u) / 16u * 16u);
+    if (n <= 1280) return (n + 63u) / 64u * 64u;
+    unsigned cls = 2048;
+    while (cls < n) cls <<= 1;
+    return cls;
+}
+
+// h.d_indptr (shard-local, nloc + 1), h.d_indices, h.d_values are on the device: per segment, sort the rows by length
+// (longest first, equal lengths in row order), build the row descriptors on the device and the length bins on the host
+// (from the sorted lengths: 4 bytes per row come back over PCIe, the only host work left is one linear scan).
+int finish_half(Half& h, hipStream_t stream, int nseg = 1)
+{
+    const size_t nloc = h.row_end - h.row_begin;
+    unsigned* d_len = nullptr;
+    if (h.d_perm == nullptr) HIP_TRY(hipMalloc(&h.d_perm, sizeof(unsigned) * (nloc ? nloc : 1)));
+    if (h.d_desc == nullptr) HIP_TRY(hipMalloc(&h.d_desc, sizeof(RowDesc) * (nloc ? nloc : 1)));
+    h.segs.clear();
+    nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(nseg, 1), std::max<size_t>(nloc, 1)));
+    if (nloc == 0) { h.segs.push_back({ 0u, 0u, {} }); return 0; }
+    HIP_TRY(hipMalloc(&d_len, sizeof(unsigned) * nloc));
+    for (int j = 0; j < nseg; j++) {
+        const size_t lo = nloc * (size_t)j / (size_t)nseg, hi = nloc * (size_t)(j + 1) / (size_t)nseg;   // == dist.segment_of
+        h.segs.push_back({ (unsigned)lo, (unsigned)hi, {} });
+        if (hi > lo && poismf_hip_device_sort_rows(h.d_indptr + lo, hi - lo, (unsigned)lo, h.d_perm + lo, d_len + lo, stream)) { (void)hipFree(d_len); return 1; }
+    }
+    const unsigned grid = (unsigned)std::min<size_t>((nloc + 255) / 256, 2048);
+    hipLaunchKernelGGL(row_desc_kernel, dim3(grid), dim3(256), 0, stream, h.d_indptr, h.d_perm, nloc, h.d_desc);
+    std::vector<unsigned> len(nloc);
+    hipError_t e = hipMemcpyAsync(len.data(), d_len, sizeof(unsigned) * nloc, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_len);
+    HIP_TRY(e);
+    for (auto& sg : h.segs) {
+        for (size_t i = sg.row_lo; i < sg.row_hi; i++) {
+            const unsigned cls = length_class(len[i]);
+            if (sg.bins.empty() || cls != sg.bins.back().cls) sg.bins.push_back({ (unsigned)i, 0u, len[i], cls });   // sorted: the first row of a bin is its longest
+            sg.bins.back().count++;
+        }
+    }
+    return 0;
+}
+
+// Upload rows [r0, r1) of a host CSR (size_t indices) with shard-local pointers; the indices are narrowed to u32 on
+// the device (the binding rejects dimensions above INT_MAX, ref: poismf_c_wrapper.pxi:78-80).
+int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* indptr, const sparse_ix* indices,
+               size_t dimM, size_t dimF, size_t r0, size_t r1)
+{
+    static_assert(sizeof(sparse_ix) == sizeof(unsigned long long), "host indices are 64-bit");
+    h.dimM = dimM; h.dimF = dimF; h.row_begin = r0; h.row_end = r1;
+    const size_t nloc = r1 - r0;
+    const size_t base = indptr[r0];
+    h.nnz = indptr[r1] - base;
+    HIP_TRY(hipMalloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1)));
+    HIP_TRY(hipMalloc(&h.d_indices, sizeof(unsigned) * (h.nnz ? h.nnz : 1)));
+    HIP_TRY(hipMalloc(&h.d_values, sizeof(real_t) * (h.nnz ? h.nnz : 1)));
+    HIP_TRY(hipMemcpyAsync(h.d_indptr, indptr + r0, sizeof(unsigned long long) * (nloc + 1), hipMemcpyHostToDevice, stream));
+    if (base != 0) {
+        hipLaunchKernelGGL(rebase_indptr_kernel, dim3((unsigned)std::min<size_t>((nloc + 256) / 256, 2048)), dim3(256), 0, stream, h.d_indptr, nloc + 1,
+                           (unsigned long long)base);
+    }
+    if (h.nnz) {
+        unsigned long long* d_wide = nullptr;
+        HIP_TRY(hipMalloc(&d_wide, sizeof(unsigned long long) * h.nnz));
+        hipError_t e = hipMemcpyAsync(d_wide, indices + base, sizeof(unsigned long long) * h.nnz, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && poismf_hip_device_narrow(d_wide, h.nnz, h.d_indices, stream)) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipMemcpyAsync(h.d_values, val + base, sizeof(real_t) * h.nnz, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_wide);
+        HIP_TRY(e);
+    }
+    return finish_half(h, stream);
+}
+
+bool prefetch_enabled()
+{
+    static const bool off = getenv("POISMF_HIP_NO_PREFETCH") != nullptr;  // testing knob
+    return !off;
+}
+
+TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_pq)
+{
+    TileGeom g;
+    g.k = (int)k;
+    g.pq_cap = 0;
+    g.prefetch = 0;
+    g.zero_row = 0;
+    g.ldF = (int)k;
+    g.s_load = (int)((k * sizeof(real_t) + 15) / 16);
+    g.s_stride = g.s_load | 1;
+    g.group = g.s_load <= 16 ? 16 : (g.s_load <= 32 ? 32 : 64);
+    // tile capacity: whole rows of this bin if that fits the per-wave budget, else stream in chunks.
+    // A single-pass solver (PG with one update) gains nothing from residency: keep tiles small there
+    // so that many waves per CU keep gathers in flight.
+    const unsigned want = std::max(16u, bin_max_nnz);
+    // chunk for streamed rows: ~14 KiB of tile per wave keeps >= 10 waves per CU gathering (measured on C2:
+    // 128-nonzero chunks 1.46 ms per sweep, 64 or 32: 0.80-0.85 ms)
+    unsigned stream_chunk = (unsigned)(14336 / ((size_t)g.s_stride * 16)) / 16 * 16;
+    stream_chunk = std::min(128u, std::max(16u, stream_chunk));
+    // multi-pass solvers: at least 32 nonzeros per chunk while four such tiles still fit a CU's LDS next to everything
+    // else (C5, TNCG fp64 k = 100: 16 -> 32 nonzeros takes the B half from 1091 to 956 ms; 48: 1051)
+    if (!single_pass && (size_t)32 * g.s_stride * 16 <= 28 * 1024) stream_chunk = std::max(stream_chunk, 32u);
+    // with the next chunk's tile requested a chunk ahead (row_eval.hpp, PF) a larger chunk amortises the per-chunk
+    // overhead without exposing its gather: as many nonzeros as the PMF_PRE slots per lane in flight hold
+    // (C3 B half, CG fp64: 32 nonzeros without prefetch 103.9 ms, with 96.6; 48 with prefetch 82.6; 64 without 111.7)
+    if (!single_pass && prefetch_enabled() && ((size_t)g.s_load == (size_t)SPECIAL_SL_A || (size_t)g.s_load == (size_t)SPECIAL_SL_B))
+        stream_chunk = std::max(stream_chunk, std::max(16u, (unsigned)(PMF_PRE * WAVE / g.s_load) / 16 * 16));
+    if (const char* e = getenv("POISMF_HIP_STREAM_CHUNK")) stream_chunk = (unsigned)std::max(16, atoi(e));  // tuning knob
+    unsigned cap = want;
+    g.resident = 1;
+    TileGeom probe = g;
+    probe.cap = (int)cap;
+    if (lds_bytes_per_wave(probe, sizeof(real_t)) > LDS_RESIDENT_LIMIT || (single_pass && cap > stream_chunk)) {
+        cap = stream_chunk;
+        probe.cap = (int)cap;
+        while (cap > 16 && lds_bytes_per_wave(probe, sizeof(real_t)) > LDS_RESIDENT_LIMIT) { cap /= 2; probe.cap = (int)cap; }
+        g.resident = 0;
+    }
+    g.cap = (int)cap;
+    // CG: cache T.x and T.d per nonzero when both fit next to the tile (up to 48 KiB for the pair); longer rows
+    // fall back to the direct line search
+    static const bool no_cache = getenv("POISMF_HIP_CG_NOCACHE") != nullptr;  // testing knob
+    // Only for streamed rows: there every line-search trial would otherwise be a fresh gather from L2/HBM
+    // (C3 B half: 247 -> 146 ms).  For LDS-resident rows a trial is a cheap pass over the tile already and the
+    // cached variant buys nothing: it halves the passes over the tile (C2 CG fp64: 20 -> 10 per row) and the sweep takes
+    // the same 10.3 ms -- those rows are bound by the solver's chain of k-vector reductions and scalar decisions at one
+    // wave per SIMD, not by the tile passes (POISMF_HIP_CG_CACHE_RESIDENT=1 switches it on for them).
+    static const bool cache_resident = getenv("POISMF_HIP_CG_CACHE_RESIDENT") != nullptr;  // tuning knob
+    if (want_pq && !no_cache && (!g.resident || cache_resident) && (size_t)2 * bin_max_nnz * sizeof(real_t) <= 48 * 1024)
+        g.pq_cap = (int)((bin_max_nnz + 15u) / 16u * 16u);
+    g.prefetch = (!g.resident && prefetch_enabled()) ? 1 : 0;
+    return g;
+}
+
+}  // namespace
+
+namespace {
+
+// column-sum kernels: elements per lane in the plain lane <-> element layout
+int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : (k <= 512 ? 8 : 0))); }
+template <int NC> int launch_colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
+{
+    const int nw = (int)std::min<size_t>((size_t)s->colsum_waves, std::max<size_t>((n + COLSUM_BLOCK_WAVES - 1) / COLSUM_BLOCK_WAVES, 1));
+    hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(nw), dim3(WAVE * COLSUM_BLOCK_WAVES), 0, s->stream, M, n, (int)s->k,
+                       s->d_partial);
+    hipLaunchKernelGGL((colsum_final_kernel<real_t, NC>), dim3(1), dim3(WAVE * COLSUM_FINAL_WAVES), 0, s->stream, s->d_partial, nw, (int)s->k, l1,
+                       scale, nscale, s->d_bsum);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
+{
+    switch (nc_for_k(s->k)) {
+        case 1: return launch_colsum<1>(s, M, n, l1, scale, nscale);
+        case 2: return launch_colsum<2>(s, M, n, l1, scale, nscale);
+        case 4: return launch_colsum<4>(s, M, n, l1, scale, nscale);
+        case 8: return launch_colsum<8>(s, M, n, l1, scale, nscale);
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Everything of a session except the two halves of X: streams, the replicated factors (+ their line-padded gather
+// copies), column-sum scratch.  On failure the partly built session is destroyed and nullptr returned.
+static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, size_t dimB, size_t k)
+{
+    if (k == 0 || slots_per_lane(k) == 0 || nc_for_k(k) == 0) {
+        fprintf(stderr, "poismf_hip: k = %zu is outside the supported range (1..%d)\n", k, 128 * SLOT_ELEMS);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    poismf_hip_session* s = new (std::nothrow) poismf_hip_session();
+    if (!s) return nullptr;
+    s->device = device;
+    {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) s->num_cu = n;
+    }
+    s->stream = (hipStream_t)stream;
+    auto fail = [&]() -> poismf_hip_session* { poismf_hip_session_destroy(s); return nullptr; };
+    if (s->stream == nullptr) {  // no stream given: the session owns a non-blocking stream (NOT the legacy default stream)
+        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return nullptr; }
+        s->owns_stream = true;
+    }
+    s->dimA = dimA; s->dimB = dimB; s->k = k;
+    // behind each factor: one all-zero row (the register engine points the unused steps of a row at it) + 16 B so that
+    // the last 16-byte slot of the last row stays in bounds
+    const size_t slack = k * sizeof(real_t) + 16;
+    if (hipMalloc(&s->dA, dimA * k * sizeof(real_t) + slack) != hipSuccess) return fail();
+    if (hipMalloc(&s->dB, dimB * k * sizeof(real_t) + slack) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->dA, 0, dimA * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->dB, 0, dimB * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
+    {
+        // A gathered row of B bytes at an arbitrary 8-byte offset touches (B + 120) / 128 lines of 128 bytes on average;
+        // in a copy whose rows start on line boundaries it touches ceil(B / 128).  k = 50 fp32: 2.5 -> 2 lines.
+        const size_t rowb = k * sizeof(real_t);
+        size_t padb = (rowb + 127) / 128 * 128;
+        static const bool no_pad = getenv("POISMF_HIP_NO_PAD") != nullptr;  // testing knob
+        const bool line_pad = !no_pad && padb != rowb && (double)padb <= 0.9 * (double)(rowb + 120);
+        // and a row that does not end on a 16-byte slot boundary is padded to one in any case: the gathers fetch whole
+        // slots and rely on the excess of the last one being zero
+        if (!line_pad) padb = (rowb + 15) / 16 * 16;
+        if (padb != rowb) {
+            s->ld = padb / sizeof(real_t);
+            const size_t pslack = padb + 16;
+            if (hipMalloc(&s->dAp, dimA * padb + pslack) != hipSuccess) return fail();
+            if (hipMalloc(&s->dBp, dimB * padb + pslack) != hipSuccess) return fail();
+            if (hipMemsetAsync(s->dAp, 0, dimA * padb + pslack, s->stream) != hipSuccess) return fail();
+            if (hipMemsetAsync(s->dBp, 0, dimB * padb + pslack, s->stream) != hipSuccess) return fail();
+        }
+    }
+    if (hipMalloc(&s->d_bsum, k * sizeof(real_t) + slack) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t)) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_counter, sizeof(unsigned)) != hipSuccess) return fail();
+    if (hipMalloc(&s->d_queue, sizeof(unsigned) * MAX_LAUNCHES) != hipSuccess) return fail();
+    if (hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail();
+    if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) return fail();
+    if (hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail();
+    return s;
+}
+
+int poismf_hip_session_create(poismf_hip_session** out, int device, void* stream, const real_t* Xr,
+                              const sparse_ix* Xr_indptr, const sparse_ix* Xr_indices, const real_t* Xc,
+                              const sparse_ix* Xc_indptr, const sparse_ix* Xc_indices, size_t dimA, size_t dimB, size_t k,
+                              size_t rowA_begin, size_t rowA_end, size_t rowB_begin, size_t rowB_end)
+{
+    *out = nullptr;
+    if (rowA_end > dimA || rowB_end > dimB || rowA_begin > rowA_end || rowB_begin > rowB_end) return 1;
+    poismf_hip_session* s = session_alloc(device, stream, dimA, dimB, k);
+    if (!s) return 1;
+    auto fail = [&]() { poismf_hip_session_destroy(s); return 1; };
+    // half 0 updates B: rows of the CSC; half 1 updates A: rows of the CSR
+    if (Xc_indptr != nullptr &&
+        build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, rowB_begin, rowB_end)) return fail();
+    if (build_half(s->half[1], s->stream, Xr, Xr_indptr, Xr_indices, dimA, dimB, rowA_begin, rowA_end)) return fail();
+    *out = s;
+    return 0;
+}
+
+// One orientation of a device COO -> the half's own (exactly sized) CSR arrays, rows [m0, m1) only.
+static int half_from_device_coo(Half& h, hipStream_t stream, const unsigned* d_major, const unsigned* d_minor, const real_t* d_val, size_t n,
+                                size_t dimM, size_t dimF, size_t m0, size_t m1)
+{
+    h.dimM = dimM; h.dimF = dimF; h.row_begin = m0; h.row_end = m1;
+    const size_t nloc = m1 - m0;
+    unsigned* t_idx = nullptr;
+    real_t* t_val = nullptr;
+    HIP_TRY(hipMalloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1)));
+    hipError_t e = hipMalloc(&t_idx, sizeof(unsigned) * n);
+    if (e == hipSuccess) e = hipMalloc(&t_val, sizeof(real_t) * n);
+    size_t uniq = 0;
+    int rc = e != hipSuccess;
+    if (!rc) rc = poismf_hip_device_coo_to_cs(d_major, d_minor, d_val, n, m0, m1, t_idx, t_val, h.d_indptr, &uniq, stream);
+    if (!rc) {
+        h.nnz = uniq;
+        // the conversion's outputs have room for all n triplets; the session keeps exactly sized copies
+        if (hipMalloc(&h.d_indices, sizeof(unsigned) * (uniq ? uniq : 1)) != hipSuccess ||
+            hipMalloc(&h.d_values, sizeof(real_t) * (uniq ? uniq : 1)) != hipSuccess ||
+            hipMemcpyAsync(h.d_indices, t_idx, sizeof(unsigned) * uniq, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+            hipMemcpyAsync(h.d_values, t_val, sizeof(real_t) * uniq, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            rc = 1;
+    }
+    if (t_idx) (void)hipFree(t_idx);
+    if (t_val) (void)hipFree(t_val);
+    return rc ? 1 : finish_half(h, stream);
+}
+
+int poismf_hip_session_create_coo(poismf_hip_session** out, int device, void* stream, const sparse_ix* row, const sparse_ix* col,
+                                  const real_t* val, size_t n, size_t dimA, size_t dimB, size_t k, size_t rowA_begin,
+                                  size_t rowA_end, size_t rowB_begin, size_t rowB_end)
+{
+    *out = nullptr;
+    if (n == 0 || n > 0xffffffffull || dimA > 0x7fffffffull || dimB > 0x7fffffffull) return 1;
+    if (rowA_end > dimA || rowB_end > dimB || rowA_begin > rowA_end || rowB_begin > rowB_end) return 1;
+    poismf_hip_session* s = session_alloc(device, stream, dimA, dimB, k);
+    if (!s) return 1;
+    unsigned *d_row = nullptr, *d_col = nullptr;
+    real_t* d_val = nullptr;
+    int rc = 1;
+    do {
+        if (hipMalloc(&d_row, sizeof(unsigned) * n) != hipSuccess || hipMalloc(&d_col, sizeof(unsigned) * n) != hipSuccess ||
+            hipMalloc(&d_val, sizeof(real_t) * n) != hipSuccess)
+            break;
+        {
+            std::vector<unsigned> h32;
+            try { h32.resize(n); } catch (const std::bad_alloc&) { break; }
+            for (size_t i = 0; i < n; i++) h32[i] = (unsigned)row[i];
+            if (hipMemcpy(d_row, h32.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice) != hipSuccess) break;
+            for (size_t i = 0; i < n; i++) h32[i] = (unsigned)col[i];
+            if (hipMemcpy(d_col, h32.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        }
+        if (hipMemcpy(d_val, val, sizeof(real_t) * n, hipMemcpyHostToDevice) != hipSuccess) break;
+        // half 0 updates B: the CSC (major = column); half 1 updates A: the CSR (major = row)
+        if (half_from_device_coo(s->half[0], s->stream, d_col, d_row, d_val, n, dimB, dimA, rowB_begin, rowB_end)) break;
+        if (half_from_device_coo(s->half[1], s->stream, d_row, d_col, d_val, n, dimA, dimB, rowA_begin, rowA_end)) break;
+        rc = 0;
+    } while (0);
+    if (d_row) (void)hipFree(d_row);
+    if (d_col) (void)hipFree(d_col);
+    if (d_val) (void)hipFree(d_val);
+    if (rc) { poismf_hip_session_destroy(s); return 1; }
+    *out = s;
+    return 0;
+}
+
+void poismf_hip_session_destroy(poismf_hip_session* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    if (s->aux_stream) (void)hipStreamSynchronize(s->aux_stream);
+    for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
+    s->prof.clear();
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
+    if (s->owns_stream) (void)hipStreamDestroy(s->stream);
+    free_half(s->half[0]);
+    free_half(s->half[1]);
+    if (s->dA) (void)hipFree(s->dA);
+    if (s->dB) (void)hipFree(s->dB);
+    if (s->dAp) (void)hipFree(s->dAp);
+    if (s->dBp) (void)hipFree(s->dBp);
+    if (s->d_bsum) (void)hipFree(s->d_bsum);
+    if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->d_queue) (void)hipFree(s->d_queue);
+    delete s;
+}
+
+// Whoever asks for the device pointers may write through them: the padded gather copies are re-derived afterwards.
+real_t* poismf_hip_session_A(poismf_hip_session* s) { s->padded_fresh[1] = false; return s->dA; }
+real_t* poismf_hip_session_B(poismf_hip_session* s) { s->padded_fresh[0] = false; return s->dB; }
+// ... and whoever keeps such a pointer says so after every later write (which = 0: B was written, 1: A)
+void poismf_hip_session_factors_dirty(poismf_hip_session* s, int which) { s->padded_fresh[which ? 1 : 0] = false; }
+void* poismf_hip_session_stream(poismf_hip_session* s) { return (void*)s->stream; }
+size_t poismf_hip_session_nnz(poismf_hip_session* s, int which) { return s->half[which ? 1 : 0].nnz; }
+
+#ifdef PMF_TIMING
+// development-only export (not in the header): read and reset the phase timers (they live in the row-kernel translation unit)
+}
+int pmf_read_timing(unsigned long long* out);
+extern "C" {
+__attribute__((visibility("default"))) void poismf_hip_debug_timing(unsigned long long* out) { (void)pmf_read_timing(out); }
+#endif
+
+// Largest distance in ulps between this library's double log (wave_ops.hpp) and the device library's over n sample
+// arguments, and the number of special arguments (+-0, -1, +-inf, NaN) on which they disagree.
+int poismf_hip_selftest_log(size_t n, unsigned long long* worst_ulp, unsigned* mismatched_specials)
+{
+    unsigned long long* d_w = nullptr;
+    unsigned* d_m = nullptr;
+    HIP_TRY(hipMalloc(&d_w, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&d_m, sizeof(unsigned)));
+    HIP_TRY(hipMemset(d_w, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d_m, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(selftest_log_kernel, dim3(256 * 8), dim3(256), 0, 0, (unsigned long long)n, d_w, d_m);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(worst_ulp, d_w, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mismatched_specials, d_m, sizeof(unsigned), hipMemcpyDeviceToHost));
+    (void)hipFree(d_w);
+    (void)hipFree(d_m);
+    return 0;
+}
+
+int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, const real_t* B_host)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(s->dA, A_host, s->dimA * s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->dB, B_host, s->dimB * s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->padded_fresh[0] = s->padded_fresh[1] = false;
+    return 0;
+}
+
+int poismf_hip_session_get_factors(poismf_hip_session* s, real_t* A_host, real_t* B_host)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(A_host, s->dA, s->dimA * s->k * sizeof(real_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(B_host, s->dB, s->dimB * s->k * sizeof(real_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+void poismf_hip_session_profile(poismf_hip_session* s, int enable)
+{
+    (void)hipStreamSynchronize(s->stream);
+    for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
+    s->prof.clear();
+    s->profiling = enable != 0;
+    for (Half& h : s->half) {
+        const size_t n = h.row_end - h.row_begin;
+        if (s->profiling && h.d_eval_rows == nullptr && n > 0 && hipMalloc(&h.d_eval_rows, sizeof(unsigned) * n) != hipSuccess) h.d_eval_rows = nullptr;
+        if (h.d_eval_rows != nullptr) (void)hipMemsetAsync(h.d_eval_rows, 0, sizeof(unsigned) * n, s->stream);
+    }
+}
+
+int poismf_hip_session_kernel_time(poismf_hip_session* s, int which, double* total_ms, size_t* launches)
+{
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    double tot = 0;
+    size_t n = 0;
+    for (auto& p : s->prof) {
+        if (p.which != which) continue;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.t0, p.t1));
+        tot += ms;
+        n++;
+    }
+    *total_ms = tot;
+    *launches = n;
+    return 0;
+}
+
+int poismf_hip_session_eval_stats(poismf_hip_session* s, int which, unsigned long long* tile_passes, unsigned long long* nnz_passes)
+{
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    Half& h = s->half[which ? 1 : 0];
+    const size_t n = h.row_end - h.row_begin;
+    *tile_passes = 0;
+    *nnz_passes = 0;
+    if (h.d_eval_rows == nullptr || n == 0) return 0;
+    std::vector<unsigned> ev(n);
+    std::vector<unsigned long long> ptr(n + 1);
+    HIP_TRY(hipMemcpy(ev.data(), h.d_eval_rows, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ptr.data(), h.d_indptr, sizeof(unsigned long long) * (n + 1), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        *tile_passes += ev[i];
+        *nnz_passes += (unsigned long long)ev[i] * (ptr[i + 1] - ptr[i]);
+    }
+    return 0;
+}
+
+// bsum_override != nullptr: use this HOST k-vector (already carrying l1 and any PG scaling) instead of the column
+// sums of the fixed factor; neg_step_override then replaces -step_size as the PG scale of the per-row Bsum_w.
+// seg < 0: every segment of the shard; seg >= 0: that segment only -- segment 0 then also runs the prologue (column sums,
+// refresh of the padded gather copy, reset of the early-stop counter), and the counter is read by whichever call passes
+// n_unchanged (the last segment).
+static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_params* p, real_t step_size, real_t cnst_div,
+                           size_t* n_unchanged, const real_t* bsum_override, real_t neg_step_override, real_t neg_step2 = (real_t)1,
+                           int seg = -1)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    which = which ? 1 : 0;
+    Half& h = s->half[which];
+    real_t* M = which ? s->dA : s->dB;
+    const real_t* F = which ? s->dB : s->dA;
+    const size_t dimF = which ? s->dimB : s->dimA;
+    const bool is_pg = p->method == POISMF_PG;
+    const bool weighted = p->w_mult != (real_t)1.;
+    if (seg >= (int)h.segs.size()) return 1;
+    const bool prologue = seg <= 0;
+
+    // column sums of the fixed factor (+ l1), with the PG pre-scaling when w == 1:
+    //   B half: * (-step)            ref: src/poismf.c:523-524
+    //   A half: * (-step) twice      ref: src/poismf.c:573-577 (quirk Q1)
+    real_t neg_step = -step_size;
+    if (bsum_override != nullptr) {
+        neg_step = neg_step_override;
+        HIP_TRY(hipMemcpyAsync(s->d_bsum, bsum_override, s->k * sizeof(real_t), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));  // the caller's host vector may change right after this call
+    } else if (prologue) {
+        int nscale = 0;
+        if (is_pg && !weighted) nscale = which ? 2 : 1;
+        if (colsum(s, F, dimF, p->l1_reg, neg_step, nscale)) return 1;
+    }
+
+    // the gathers read the line-padded copy of the fixed factor when the session keeps one
+    const real_t* Fg = F;
+    size_t ldF = s->k;
+    real_t* Mp = nullptr;
+    if (s->ld != 0) {
+        // The padded copy of F is current only if this session's own previous half-sweep rewrote ALL of F (its row
+        // kernels store every updated row to both copies).  Anything else -- factors set by the caller, a shard
+        // exchange between GPUs writing into the compact factor -- is picked up by re-padding the whole factor.
+        real_t* Fp = which ? s->dBp : s->dAp;
+        if (prologue && !s->padded_fresh[which ? 0 : 1]) {
+            const size_t total = dimF * s->k;
+            const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)s->num_cu * 16);
+            if (blocks > 0) hipLaunchKernelGGL((repad_kernel<real_t>), dim3(blocks), dim3(256), 0, s->stream, F, Fp, dimF, (int)s->k, (int)s->ld);
+            HIP_TRY(hipGetLastError());
+        }
+        Fg = Fp;
+        ldF = s->ld;
+        Mp = which ? s->dAp : s->dBp;
+        if (prologue) {
+            s->padded_fresh[which ? 0 : 1] = true;   // the copy of F was just re-derived (or was current)
+            s->padded_fresh[which ? 1 : 0] = h.row_begin == 0 && h.row_end == h.dimM;
+        }
+    }
+
+    HalfArgs<real_t> a;
+    a.M = M; a.F = Fg;
+    a.Mp = Mp; a.ldM = (int)s->ld;
+    a.indptr = h.d_indptr; a.indices = h.d_indices; a.values = h.d_values; a.perm = h.d_perm; a.desc = h.d_desc;
+    a.row_offset = (unsigned)h.row_begin;
+    a.bsum = s->d_bsum;
+    a.P.l2 = p->l2_reg; a.P.w = p->w_mult;
+    a.P.step = step_size * p->w_mult;  // ref: src/poismf.c:151
+    a.P.cnst_div = cnst_div;
+    a.P.neg_step = neg_step;
+    a.P.neg_step2 = neg_step2;
+    a.P.maxupd = (int)std::min<size_t>(p->maxupd, 0x7fffffff);
+    a.P.limit_step = p->limit_step;
+    a.P.max_cg_it = (int)std::max(1.0, std::min(50.0, (double)(real_t)s->k / 2.0));  // ref: src/poismf.c:342
+    a.reuse_prev = p->reuse_prev;
+    a.early_stop = (p->method == POISMF_TNCG) && p->early_stop && (n_unchanged != nullptr || seg >= 0);
+    a.n_unchanged = s->d_counter;
+    a.eval_rows = s->profiling ? h.d_eval_rows : nullptr;
+    if (a.early_stop && prologue) HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned), s->stream));
+
+    const bool single_pass = is_pg && p->maxupd <= 1 && !weighted;
+    ProfRec rec{};
+    if (s->profiling) {
+        HIP_TRY(hipEventCreate(&rec.t0));
+        HIP_TRY(hipEventCreate(&rec.t1));
+        rec.which = which;
+        HIP_TRY(hipEventRecord(rec.t0, s->stream));
+    }
+    // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
+    // solver) are merged into one launch.
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; };
+    std::vector<Launch> launches;
+    static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
+    // register engine: factor rows of at most 16 slots, and 24-bit row ids / 32-bit byte offsets into the factor
+    const bool reg_ok = !no_reg && (s->k * sizeof(real_t) + 15) / 16 <= 16 &&
+                        dimF < ((size_t)1 << 24) && (dimF + 1) * ldF * sizeof(real_t) + 16 < ((size_t)1 << 32);
+    static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
+    unsigned long_thr = LONG_ROW_NNZ;
+    if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
+    std::vector<Bin> bins;   // of the segments this call runs, in order
+    for (size_t j = 0; j < h.segs.size(); j++)
+        if (seg < 0 || (size_t)seg == j) bins.insert(bins.end(), h.segs[j].bins.begin(), h.segs[j].bins.end());
+    for (const Bin& b : bins) {
+        TileGeom g = plan_geom(s->k, b.cls, single_pass, p->method == POISMF_CG && p->limit_step);
+        if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
+        if (reg_ok && b.cls <= reg_nnz_max(p->method)) {
+            // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
+            // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
+            const int S = reg_steps_for(b.max_nnz);
+            if (!launches.empty() && launches.back().nw == 1 && launches.back().reg_S >= S &&
+                (launches.back().reg_S == S || b.count < 4096u) && launches.back().begin + launches.back().count == b.begin)
+                launches.back().count += b.count;
+            else
+                launches.push_back({ b.begin, b.count, g, 1, S });
+            continue;
+        }
+        if (reg_ok && b.cls <= regw_nnz_max(p->method)) {
+            // medium rows: 2, 4 or 8 waves share a row, each keeps its part of the tile in registers
+            const int nw = regw_waves_for(b.cls, p->method);
+            const int S = regw_steps_for(b.max_nnz, nw);
+            if (!launches.empty() && launches.back().nw == nw && launches.back().reg_S >= S &&
+                (launches.back().reg_S == S || b.count < 2048u) && launches.back().begin + launches.back().count == b.begin)
+                launches.back().count += b.count;
+            else
+                launches.push_back({ b.begin, b.count, g, nw, S });
+            continue;
+        }
+        if (!no_long && b.cls > long_thr) {
+            // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
+            // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
+            g.resident = 0;
+            g.prefetch = prefetch_enabled() ? 1 : 0;
+            g.pq_cap = 0;
+            int cap = 128;
+            for (;;) {
+                g.cap = cap;
+                if (cap <= 16 || lds_bytes_per_block(g, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
+                cap -= 16;
+            }
+            if (!launches.empty() && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
+                launches.back().count += b.count;
+            else
+                launches.push_back({ b.begin, b.count, g, LONG_NW, 0 });
+            continue;
+        }
+        if (!launches.empty() && launches.back().reg_S == 0 && launches.back().geom.cap == g.cap &&
+            launches.back().geom.resident == g.resident && (g.resident == 0) && g.pq_cap == 0 && launches.back().geom.pq_cap == 0 && launches.back().nw == 1 &&
+            launches.back().begin + launches.back().count == b.begin)
+            launches.back().count += b.count;
+        else
+            launches.push_back({ b.begin, b.count, g, 1, 0 });
+    }
+    static const bool static_rows = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;  // testing knob
+    const bool dynamic = !is_pg && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
+    if (dynamic) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
+    // the few workgroup-per-row launches of the power-law tail occupy a few dozen CUs for a long time: run them on a
+    // second stream beside the other bins (fork after the column sums, join before anything reads the result)
+    // Several launches per half: they also alternate between the two streams (each to the one with less work queued so
+    // far), so that the tail of one bin overlaps the start of the next.
+    // (off by default: overlapping launches make the per-kernel durations of a profile overlap too)
+    static const bool no_fork = getenv("POISMF_HIP_NO_FORK") != nullptr;  // testing knob
+    static const bool fork_bins = getenv("POISMF_HIP_FORK_BINS") != nullptr;  // tuning knob
+    bool any_long = false;
+    for (const Launch& L : launches) any_long = any_long || (L.nw > 1 && L.reg_S == 0);
+    const bool forked = !no_fork && launches.size() > 1 && (any_long || fork_bins);
+    hipStream_t long_stream = forked ? s->aux_stream : s->stream;
+    double queued[2] = { 0.0, 0.0 };
+    if (forked) {
+        HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
+    }
+    int launch_no = 0;
+    if (prologue) s->last_plan[which].clear();
+    for (const Launch& L : launches) {
+        {
+            char txt[192];
+            const char* m = is_pg ? "pg" : p->method == POISMF_CG ? "cg" : "tncg";
+            const char* t = sizeof(real_t) == 4 ? "float" : "double";
+            if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
+            else if (L.reg_S > 0) snprintf(txt, sizeof txt, "half_sweep_regw_kernel<%s,%s,S=%d,NW=%d> rows=%u;", t, m, L.reg_S, L.nw, L.count);
+            else snprintf(txt, sizeof txt, "half_sweep_kernel<%s,%s,NW=%d,%s cap=%d> rows=%u;", t, m, L.nw, L.geom.resident ? "resident" : "streamed", L.geom.cap, L.count);
+            s->last_plan[which] += txt;
+        }
+        a.queue = dynamic ? s->d_queue + launch_no : nullptr;
+        launch_no++;
+        a.perm_begin = L.begin;
+        a.nrows = L.count;
+        a.geom = L.geom;
+        a.geom.zero_row = (unsigned)dimF;
+        a.geom.ldF = (int)ldF;
+        const size_t lds = lds_bytes_per_block(a.geom, sizeof(real_t), L.nw);
+        const unsigned waves_per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / lds));
+        // Waves launched per resident wave slot.  Rows pulled from the queue balance themselves: 2 is enough.  Rows dealt
+        // out statically come in nnz-descending order, so wave 0 always gets the longest of each round; many short
+        // waves let the dispatcher even that out (measured on C2, PG(10): 2 -> 1.214 ms, 8 -> 1.165, 32 -> 1.146).
+        // The single-wave register kernels are always dealt out this way: with ~1 row per wave the hardware dispatcher IS
+        // the queue (CG fp32 on C2: 3.87 ms with tickets, 3.35 ms without).
+        const bool one_wave_reg = L.reg_S > 0 && L.nw == 1;
+        if (one_wave_reg) a.queue = nullptr;
+        unsigned grid_mult = one_wave_reg ? 32 : 2;
+        if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
+        const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
+        int rc = 1;
+        const int lane_stream = (forked && fork_bins && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
+        hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
+        queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
+        {
+            OneLaunch o;
+            o.reg_S = L.reg_S; o.nw = L.nw; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
+            static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
+            o.generic_only = generic_only;
+            o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
+            o.lds = lds; o.grid = grid; o.grid_mult = grid_mult;
+            o.device = s->device; o.num_cu = s->num_cu;
+            rc = launch_one(p->method, o, a);
+        }
+        if (rc) return 1;
+    }
+    if (forked) {
+        HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    }
+    if (s->profiling) {
+        HIP_TRY(hipEventRecord(rec.t1, s->stream));
+        s->prof.push_back(rec);
+    }
+    if (a.early_stop && n_unchanged != nullptr) {
+        unsigned cnt = 0;
+        HIP_TRY(hipMemcpyAsync(&cnt, s->d_counter, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        *n_unchanged = cnt;
+    }
+    return 0;
+}
+
+int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_params* p, real_t step_size, real_t cnst_div,
+                          size_t* n_unchanged)
+{
+    return half_sweep_impl(s, which, p, step_size, cnst_div, n_unchanged, nullptr, (real_t)0);
+}
+
+// The launches of the most recent half-sweep of half `which` ("kernel<instance> rows=N;" per launch), NUL-terminated,
+// truncated to cap bytes.  Returns the untruncated length.
+size_t poismf_hip_session_plan(poismf_hip_session* s, int which, char* buf, size_t cap)
+{
+    const std::string& t = s->last_plan[which ? 1 : 0];
+    if (cap > 0) {
+        const size_t n = std::min(cap - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return t.size();
+}
+
+int poismf_hip_session_set_segments(poismf_hip_session* s, int which, int nseg)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    Half& h = s->half[which ? 1 : 0];
+    if (h.d_indptr == nullptr || finish_half(h, s->stream, nseg)) return -1;
+    return (int)h.segs.size();
+}
+
+int poismf_hip_session_segment_rows(poismf_hip_session* s, int which, int seg, size_t* row_begin, size_t* row_end)
+{
+    const Half& h = s->half[which ? 1 : 0];
+    if (seg < 0 || seg >= (int)h.segs.size()) return 1;
+    *row_begin = h.row_begin + h.segs[seg].row_lo;
+    *row_end = h.row_begin + h.segs[seg].row_hi;
+    return 0;
+}
+
+int poismf_hip_half_sweep_segment(poismf_hip_session* s, int which, const poismf_hip_params* p, real_t step_size, real_t cnst_div,
+                                  int seg, size_t* n_unchanged)
+{
+    return half_sweep_impl(s, which, p, step_size, cnst_div, n_unchanged, nullptr, (real_t)0, (real_t)1, seg);
+}
+
+// -------------------------------------------------------------------------------------------------
+// run_poismf: the drop-in                                   ref: src/poismf.c:435-632
+// -------------------------------------------------------------------------------------------------
+static volatile sig_atomic_t g_should_stop = 0;
+static bool g_handle_locked = false;
+static std::mutex g_handle_mutex;
+static void on_sigint(int)
+{
+    g_should_stop = 1;  // the reference also prints here; fprintf is not async-signal-safe, so run_poismf reports it
+}
+
+// SIGINT plumbing of one call (ref: src/poismf.c:444-455, :618-630): the first call in the process to get here installs
+// the handler and restores the previous one on the way out; nested / concurrent calls share the flag.
+namespace {
+struct SigintScope {
+    typedef void (*sig_fn)(int);
+    sig_fn old_handler = nullptr;
+    bool has_lock = false;
+    void enter()
+    {
+        std::lock_guard<std::mutex> lk(g_handle_mutex);
+        if (!g_handle_locked) {
+            g_handle_locked = true;
+            has_lock = true;
+            g_should_stop = 0;
+            old_handler = signal(SIGINT, on_sigint);
+        }
+    }
+    int leave(int ret_code, bool handle_interrupt)
+    {
+        std::lock_guard<std::mutex> lk(g_handle_mutex);
+        const bool stopped = g_should_stop != 0;
+        if (stopped) fprintf(stderr, "Error: procedure was interrupted\n");
+        if (stopped && ret_code != 1) ret_code = 2;
+        if (has_lock) {
+            signal(SIGINT, old_handler);
+            g_handle_locked = false;
+            g_should_stop = 0;
+        }
+        if (stopped && !handle_interrupt) raise(SIGINT);
+        return ret_code;
+    }
+};
+
+// The outer alternation on a session whose factors are set (ref: src/poismf.c:506-608).  Returns 0, or 1 on a device error.
+int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t numiter)
+{
+    const int method = p.method;
+    const real_t l2_reg = p.l2_reg;
+    real_t step_size = p.step_size;
+    const bool tn_stop = (method == POISMF_TNCG) && p.early_stop;
+    bool stopped_earlyA = false, stopped_earlyB = false;
+    for (size_t it = 0; it < numiter; it++) {
+        if (g_should_stop) break;
+        // quirk Q6: the divisor uses the step before halving and is reused by the A half
+        const real_t cnst_div = 1. / (1. + 2. * l2_reg * step_size);
+
+        // ---- B half first (quirk Q5) ----
+        if (!(method == POISMF_TNCG && stopped_earlyB)) {
+            size_t unchanged = 0;
+            if (poismf_hip_half_sweep(s, 0, &p, step_size, cnst_div, tn_stop ? &unchanged : nullptr)) return 1;
+            if (tn_stop) stopped_earlyB = ((double)unchanged / (double)s->dimB) >= .95;  // ref: :401-403 (quirk Q7)
+        }
+        if (method == POISMF_PG) step_size *= 0.5;  // ref: :532-533
+        if (hipStreamSynchronize(s->stream) != hipSuccess) return 1;
+        if (g_should_stop) break;
+
+        // ---- A half ----
+        if (!(method == POISMF_TNCG && stopped_earlyA)) {
+            size_t unchanged = 0;
+            if (poismf_hip_half_sweep(s, 1, &p, step_size, cnst_div, tn_stop ? &unchanged : nullptr)) return 1;
+            if (tn_stop) stopped_earlyA = ((double)unchanged / (double)s->dimA) >= .95;
+        }
+        if (hipStreamSynchronize(s->stream) != hipSuccess) return 1;
+        if (stopped_earlyA && stopped_earlyB) break;
+    }
+    return 0;
+}
+}  // namespace
+
+// run_poismf's loop on a session that already holds X and the starting factors (PoisMF.fit keeps the CSR / CSC it
+// built on the device and never takes them through host memory).  Same return codes as run_poismf.
+int poismf_hip_session_run(poismf_hip_session* s, const poismf_hip_params* p, size_t numiter, int handle_interrupt)
+{
+    SigintScope sig;
+    sig.enter();
+    int ret_code = 0;
+    if (hipSetDevice(s->device) != hipSuccess || run_alternation(s, *p, numiter)) {
+        fprintf(stderr, "Error: out of memory.\n");
+        ret_code = 1;
+    }
+    return sig.leave(ret_code, handle_interrupt != 0);
+}
+
+int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indices, real_t* B, real_t* Xc,
+               sparse_ix* Xc_indptr, sparse_ix* Xc_indices, const size_t dimA, const size_t dimB, const size_t k,
+               const real_t l2_reg, const real_t l1_reg, const real_t w_mult, real_t step_size, const int method,
+               const bool limit_step, const size_t numiter, const size_t maxupd, const bool early_stop,
+               const bool reuse_prev, const bool handle_interrupt, const int nthreads)
+{
+    (void)nthreads;
+    SigintScope sig;
+    sig.enter();
+
+    int ret_code = 0;
+    poismf_hip_session* s = nullptr;
+    int device = 0;
+    if (const char* e = getenv("POISMF_HIP_DEVICE")) device = atoi(e);
+
+    poismf_hip_params p;
+    p.l2_reg = l2_reg; p.l1_reg = l1_reg; p.w_mult = w_mult; p.step_size = step_size;
+    p.method = method; p.limit_step = limit_step; p.maxupd = maxupd;
+    p.early_stop = early_stop; p.reuse_prev = reuse_prev;
+    if (poismf_hip_session_create(&s, device, nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k, 0,
+                                  dimA, 0, dimB) ||
+        poismf_hip_session_set_factors(s, A, B) ||
+        run_alternation(s, p, numiter) ||
+        poismf_hip_session_get_factors(s, A, B)) {
+        fprintf(stderr, "Error: out of memory.\n");  // ref: :501
+        ret_code = 1;
+    }
+    poismf_hip_session_destroy(s);
+    return sig.leave(ret_code, handle_interrupt);
+}
+
+// -------------------------------------------------------------------------------------------------
+// factors_multiple: latent factors of new rows with B fixed          ref: src/pred.c:66-199
+// -------------------------------------------------------------------------------------------------
+int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* Xr, sparse_ix* Xr_indptr,
+                     sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, real_t step_size,
+                     size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean, int nthreads)
+{
+    (void)nthreads;
+    const size_t ks = (size_t)k;
+    const size_t nnz = Xr_indptr[dimA];
+    // rows start at the mean of the fitted A, except TNCG without reuse_mean (1e-3, set in the kernel); ref: :144-147
+    if (reuse_mean || method != POISMF_TNCG)
+        for (size_t r = 0; r < dimA; r++) memcpy(A + r * ks, Amean, ks * sizeof(real_t));
+    if (nnz == 0) {  // every row is empty: all three drivers zero such rows (quirk Q7)
+        memset(A, 0, dimA * ks * sizeof(real_t));
+        return 0;
+    }
+    size_t dimB = 0;  // the reference never needs the number of items; the device copy of B needs the rows in use
+    for (size_t i = 0; i < nnz; i++) dimB = std::max(dimB, (size_t)Xr_indices[i] + 1);
+
+    int device = 0;
+    if (const char* e = getenv("POISMF_HIP_DEVICE")) device = atoi(e);
+    poismf_hip_session* s = nullptr;
+    int rc = 0;
+    std::vector<real_t> bs(ks);
+    if (poismf_hip_session_create(&s, device, nullptr, Xr, Xr_indptr, Xr_indices, nullptr, nullptr, nullptr, dimA, dimB, ks, 0,
+                                  dimA, 0, 0) ||
+        hipMemcpy(s->dA, A, dimA * ks * sizeof(real_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s->dB, B, dimB * ks * sizeof(real_t), hipMemcpyHostToDevice) != hipSuccess) {
+        rc = 1;
+    } else {
+        poismf_hip_params p;
+        p.l2_reg = l2_reg; p.l1_reg = 0; p.w_mult = w_mult; p.step_size = step_size;
+        p.method = method; p.limit_step = limit_step; p.maxupd = maxupd;
+        p.early_stop = 0; p.reuse_prev = reuse_mean;
+        const bool weighted = w_mult != (real_t)1.;
+        if (method == POISMF_PG) {                                    // ref: :152-169
+            const real_t step0 = step_size;
+            for (size_t it = 0; it < niter && !rc; it++) {
+                for (size_t c = 0; c < ks; c++) bs[c] = weighted ? Bsum[c] : Bsum[c] * (-step_size);
+                const real_t cnst_div = 1. / (1. + 2. * l2_reg * step_size);
+                // w != 1: Bsum_w was scaled by -step at set-up (ref: :121-122) and again by -step here (ref: :162)
+                rc = half_sweep_impl(s, 1, &p, step_size, cnst_div, nullptr, bs.data(), -step0, weighted ? -step_size : (real_t)1);
+                step_size *= 0.5;
+            }
+        } else {
+            for (size_t c = 0; c < ks; c++) bs[c] = Bsum[c];
+            if (method == POISMF_CG) p.maxupd = maxupd * niter;      // ref: :175-178
+            rc = half_sweep_impl(s, 1, &p, step_size, (real_t)1, nullptr, bs.data(), -step_size);
+        }
+        if (!rc && (hipStreamSynchronize(s->stream) != hipSuccess ||
+                    hipMemcpy(A, s->dA, dimA * ks * sizeof(real_t), hipMemcpyDeviceToHost) != hipSuccess))
+            rc = 1;
+    }
+    poismf_hip_session_destroy(s);
+    if (rc) fprintf(stderr, "Error: out of memory.\n");
+    return rc ? 1 : 0;
+}
+
+}  // extern "C"

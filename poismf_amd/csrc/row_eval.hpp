@@ -30,7 +30,7 @@ namespace pmf {
 // Optional phase timers (build with -DPMF_TIMING): per-wave shader-clock totals of the phases of row_eval,
 // added to a global array at kernel exit.  Slots: 0 gather, 1 phase 1, 2 coef/div, 3 phase 2, 4 combine, 5 whole kernel.
 #ifdef PMF_TIMING
-__device__ unsigned long long g_pmf_timing[8];
+static __device__ unsigned long long g_pmf_timing[8];   // one per translation unit: the row kernels' unit reads its own
 #define PMF_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define PMF_T1(slot, v) tacc[slot] += __builtin_amdgcn_s_memtime() - v
 #else
@@ -73,6 +73,16 @@ struct TileGeom {
     unsigned zero_row;  // index of the all-zero row the session keeps behind the factor F (= its row count)
     int ldF;       // elements between consecutive rows of the gathered factor (k, or more in the line-padded copy)
     int prefetch;  // 1: streamed rows keep a second set of index / value buffers (next chunk's tile is requested early)
+};
+
+// Problem constants of one half-sweep that the solvers need.
+template <class T> struct RowParams {
+    T l2, w;
+    T step, cnst_div, neg_step;  // PG (step already multiplied by w, ref: src/poismf.c:151)
+    T neg_step2;                 // PG, w != 1: a second scale applied after neg_step (factors_multiple), 1 = none
+    int maxupd;
+    int limit_step;
+    int max_cg_it;               // TNC: max(1, min(50, k/2)), ref: src/poismf.c:342
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t sizeof_real)

@@ -20,15 +20,6 @@ namespace pmf {
 
 template <class T> __device__ __forceinline__ bool not_finite(T v) { return isnan(v) || isinf(v); }
 
-// Problem constants of one half-sweep that the solvers need.
-template <class T> struct RowParams {
-    T l2, w;
-    T step, cnst_div, neg_step;  // PG (step already multiplied by w, ref: src/poismf.c:151)
-    int maxupd;
-    int limit_step;
-    int max_cg_it;               // TNC: max(1, min(50, k/2)), ref: src/poismf.c:342
-};
-
 // ------------------------------------------------------------------------------------------------
 // Proximal gradient
 // ------------------------------------------------------------------------------------------------

@@ -2,15 +2,27 @@
 
 Rows of the factor being updated are independent given the full opposing factor, so each rank owns a
 contiguous range of A rows (a CSR slice) and a contiguous range of B rows (a CSC slice); both factors are
-replicated.  After each half-sweep the just-updated shard is all-gathered into every replica (RCCL over
-xGMI on the GPU, gloo in the CPU tests); the k-length column sums are recomputed locally from the
-replica, which is deterministic and needs no further collective.
+replicated.  After each half-sweep the just-updated shard travels to every other replica (RCCL over xGMI on
+the GPU, gloo in the CPU tests); the k-length column sums are recomputed locally from the replica, which is
+deterministic and needs no further collective.
 
-The per-rank compute is a *backend* with three methods::
+The exchange is written for xGMI's full mesh, not for a ring: every rank sends its rows DIRECTLY to each of its
+W - 1 peers and receives theirs straight into place in its replica -- one grouped launch of 2 (W - 1) point-to-point
+operations (`batch_isend_irecv`: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd), all 7 links of a GPU busy at
+once, no staging copy, any shard sizes (nnz-balanced ranges are unequal).  Equal contiguous shards take the
+equivalent single in-place ncclAllGather.  A half-sweep may be cut into SEGMENTS (contiguous sub-ranges of the
+rank's rows, each with its own launches): segment j's rows are exchanged on a second stream while segment j + 1
+computes, so only the last segment's transfer is exposed.
 
-    half_sweep(which, step_size, cnst_div) -> n_unchanged   # updates its shard of B (which=0) / A (which=1) in place
-    factor(which) -> torch.Tensor                            # the replicated factor this half updates, [dim x k]
+The per-rank compute is a *backend* with these methods::
+
+    half_sweep(which, step_size, cnst_div, want_unchanged=False, seg=None) -> n_unchanged
+                                        # updates its shard of B (which=0) / A (which=1) in place; seg = j: only
+                                        # segment j (the first segment also computes the column sums)
+    factor(which) -> torch.Tensor       # the replicated factor this half updates, [dim x k]
     shard(which) -> (begin, end)
+    segments(which) -> int              # optional (default 1)
+    real(v) -> float                    # optional: v rounded to the backend's real type
 
 The product backend is HipBackend (the C-ABI session, no fallback).  Tests inject their own.
 """
@@ -41,7 +53,7 @@ def balanced_ranges(indptr, nparts):
 
 def equal_ranges(n, nparts):
     """Contiguous ranges of (nearly) equal row counts (exactly equal when nparts divides n: enables the
-    single-collective all_gather_into_tensor path)."""
+    single in-place all-gather)."""
     base, rem = divmod(n, nparts)
     out, s = [], 0
     for p in range(nparts):
@@ -51,44 +63,90 @@ def equal_ranges(n, nparts):
     return out
 
 
-def exchange_shards(full, ranges, rank, group=None):
-    """All-gather: on return every rank's `full` ([dim x k], replicated) holds every rank's row range.
-    Equal ranges -> one in-place all_gather_into_tensor; otherwise one broadcast per owner."""
+def choose_ranges(counts, nparts, tolerance=0.03):
+    """Row ranges for `nparts` ranks from per-row nonzero counts: equal row counts when that leaves the nonzeros
+    balanced within `tolerance` (uniform data: the exchange is then one in-place all-gather), nnz-balanced cuts
+    otherwise (power-law data)."""
+    counts = np.asarray(counts, dtype=np.int64)
+    indptr = np.concatenate([[0], np.cumsum(counts)])
+    eq = equal_ranges(len(counts), nparts)
+    loads = [int(indptr[e] - indptr[b]) for b, e in eq]
+    if max(loads) <= (1.0 + tolerance) * (int(indptr[-1]) / nparts) + 1:
+        return eq
+    return balanced_ranges(indptr, nparts)
+
+
+def segment_of(rng, j, nseg):
+    """rows of segment j (of nseg) of the contiguous range rng = (begin, end): equal row counts"""
+    b, e = rng
+    n = e - b
+    return b + n * j // nseg, b + n * (j + 1) // nseg
+
+
+def exchange_shards(full, parts, rank, group=None):
+    """`parts[r]` = (begin, end): the rows of the replicated `full` ([dim x k]) that rank r has just updated.  On return
+    (in stream order for device tensors) every rank's `full` holds every rank's rows."""
     world = dist.get_world_size(group)
-    if world == 1 and os.environ.get("POISMF_BENCH_FORCE_DIST") != "1":
+    if world == 1:
         return
-    sizes = {e - b for b, e in ranges}
-    per_owner = full.is_cuda and dist.get_backend(group) == "gloo"   # gloo has no all_gather_into_tensor on device memory
-    if not per_owner and len(sizes) == 1 and ranges[0][0] == 0 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1)):
-        b, e = ranges[rank]
-        # staged through a copy of the shard rather than gathered in place: the extra copy is the size of one
-        # shard (C4 A half: 25 MB, ~10 us of HBM time) and avoids relying on in-place aliasing rules
-        dist.all_gather_into_tensor(full, full[b:e].clone(), group=group)
+    backend = dist.get_backend(group)
+    sizes = {e - b for b, e in parts}
+    tiled = all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+    if backend == "nccl" and len(sizes) == 1 and tiled and parts[0][1] > parts[0][0]:
+        # equal contiguous shards: ONE in-place all-gather (send buffer = this rank's slot of the receive buffer)
+        b, e = parts[rank]
+        dist.all_gather_into_tensor(full[parts[0][0]:parts[-1][1]], full[b:e], group=group)
         return
-    for owner, (b, e) in enumerate(ranges):
+    if backend == "gloo" and full.is_cuda:
+        # testing only (two processes on one GPU): gloo moves device tensors by broadcast, not by send / recv
+        for owner, (b, e) in enumerate(parts):
+            if e > b:
+                dist.broadcast(full[b:e], src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+        return
+    # any sizes: direct point-to-point, every pair at once, received in place
+    ops = []
+    mine = full[parts[rank][0]:parts[rank][1]]
+    for peer, (b, e) in enumerate(parts):
+        if peer == rank:
+            continue
+        gp = dist.get_global_rank(group, peer) if group is not None else peer
         if e > b:
-            dist.broadcast(full[b:e], src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+            ops.append(dist.P2POp(dist.irecv, full[b:e], gp, group))
+        if mine.shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, mine, gp, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
 
 
 class HipBackend:
     """The HIP session of this rank; factors are exposed as torch tensors aliasing the session's HBM."""
 
-    def __init__(self, csr, csc, dimA, dimB, k, use_float, params_kw, shardA, shardB, device):
+    def __init__(self, csr, csc, dimA, dimB, k, use_float, params_kw, shardA, shardB, device, coo=None, segments=(1, 1)):
         torch.cuda.set_device(device)
-        # A stream of its own, shared by the session's kernels and (through stream_context) by every collective on
-        # the factors: the handle of torch's default stream is 0, which the C-ABI reads as "no stream given" and
-        # answers with a private non-blocking stream -- unordered against the default stream the collectives would run on.
+        # A stream of its own, shared by the session's kernels and (through stream_context) by the collectives on
+        # the factors: the C-ABI reads a null stream handle (torch's default stream) as "no stream given" and answers
+        # with a private non-blocking stream -- unordered against the default stream the collectives would run on.
         self.stream = torch.cuda.Stream(device=device)
-        self.sess = api.Session(csr, csc, dimA, dimB, k, use_float, device=device, stream=self.stream.cuda_stream,
-                                shardA=shardA, shardB=shardB)
+        self.comm_stream = torch.cuda.Stream(device=device)
+        if coo is not None:
+            self.sess = api.Session.from_coo(coo, k, use_float, device=device, stream=self.stream.cuda_stream, shardA=shardA,
+                                             shardB=shardB)
+        else:
+            self.sess = api.Session(csr, csc, dimA, dimB, k, use_float, device=device, stream=self.stream.cuda_stream,
+                                    shardA=shardA, shardB=shardB)
         self.params = self.sess.make_params(**params_kw)
         a, b = self.sess.device_arrays()
         self._A = torch.as_tensor(a, device=f"cuda:{device}")
         self._B = torch.as_tensor(b, device=f"cuda:{device}")
         self._shards = (tuple(shardB), tuple(shardA))
+        self._nseg = [1, 1]
+        for which in (0, 1):
+            if segments[which] > 1:
+                self._nseg[which] = self.sess.set_segments(which, segments[which])
 
-    def half_sweep(self, which, step_size, cnst_div, want_unchanged=False):
-        return self.sess.half_sweep(which, self.params, step_size, cnst_div, want_unchanged)
+    def half_sweep(self, which, step_size, cnst_div, want_unchanged=False, seg=None):
+        return self.sess.half_sweep(which, self.params, step_size, cnst_div, want_unchanged, seg)
 
     def stream_context(self):
         """Run torch operations on the factors (shard exchanges, reductions) in the session's stream order."""
@@ -99,6 +157,15 @@ class HipBackend:
 
     def shard(self, which):
         return self._shards[which]
+
+    def segments(self, which):
+        return self._nseg[which]
+
+    def real(self, v):
+        return self.sess.real(v)
+
+    def factors_dirty(self, which):
+        self.sess.factors_dirty(which)
 
     def close(self):
         self.sess.close()
@@ -112,34 +179,60 @@ class ShardedAlternation:
         self.be = backend
         self.ranges = (list(rangesB), list(rangesA))
         self.method = method
-        self.l2_reg = float(l2_reg)
-        self.step = float(step_size)
+        self._real = getattr(backend, "real", float)
+        self.l2_reg = self._real(l2_reg)
+        self.step = self._real(step_size)
         self.early_stop = bool(early_stop) and method == "tncg"
         self.dims = dims  # (dimA, dimB), needed for the early-stop ratio
         self.group = group
+        self.multi = dist.is_initialized() and dist.get_world_size(group) > 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stopped = [False, False]  # [B, A]
+
+    def _exchange(self, which, j, nseg):
+        parts = [segment_of(r, j, nseg) for r in self.ranges[which]]
+        exchange_shards(self.be.factor(which), parts, self.rank, self.group)
 
     def _half(self, which, cnst_div):
         if self.method == "tncg" and self.stopped[which]:
             return
-        n = self.be.half_sweep(which, self.step, cnst_div, self.early_stop)
+        nseg = getattr(self.be, "segments", lambda w: 1)(which) if self.multi else 1
         ctx = getattr(self.be, "stream_context", None)
-        with (ctx() if ctx is not None else contextlib.nullcontext()):
-            if dist.is_initialized():
-                exchange_shards(self.be.factor(which), self.ranges[which], self.rank, self.group)
-            if self.early_stop:  # ref: src/poismf.c:395-403, summed over shards
+        comm = getattr(self.be, "comm_stream", None)
+        n = 0
+        if nseg == 1 or comm is None:
+            n = self.be.half_sweep(which, self.step, cnst_div, self.early_stop)
+            with (ctx() if ctx is not None else contextlib.nullcontext()):
+                if self.multi:
+                    self._exchange(which, 0, 1)
+        else:
+            # segment j's rows travel on the communication stream while segment j + 1 computes
+            for j in range(nseg):
+                n = self.be.half_sweep(which, self.step, cnst_div, self.early_stop and j == nseg - 1, seg=j)
+                done = torch.cuda.Event()
+                done.record(self.be.stream)
+                comm.wait_event(done)
+                with torch.cuda.stream(comm):
+                    self._exchange(which, j, nseg)
+            landed = torch.cuda.Event()
+            landed.record(comm)
+            self.be.stream.wait_event(landed)   # the next half reads the whole factor
+        if self.multi and hasattr(self.be, "factors_dirty"):
+            self.be.factors_dirty(which)
+        if self.early_stop:  # ref: src/poismf.c:395-403, summed over shards
+            with (ctx() if ctx is not None else contextlib.nullcontext()):
                 t = torch.tensor([float(n)], dtype=torch.float64, device=self.be.factor(which).device)
-                if dist.is_initialized():
+                if self.multi:
                     dist.all_reduce(t, group=self.group)
                 dim = self.dims[0] if which else self.dims[1]
                 self.stopped[which] = (float(t.item()) / float(dim)) >= .95
 
     def sweep(self):
         """One full outer iteration; returns False once TNCG early stopping has ended both halves."""
-        cnst_div = 1. / (1. + 2. * self.l2_reg * self.step)  # quirk Q6
+        # quirk Q6; evaluated as run_poismf does: real_t operands, double expression, real_t result (ref: src/poismf.c:511)
+        cnst_div = self._real(1. / (1. + 2. * self.l2_reg * self.step))
         self._half(0, cnst_div)                              # B first (quirk Q5)
         if self.method == "pg":
-            self.step *= 0.5
+            self.step = self._real(self.step * 0.5)
         self._half(1, cnst_div)
         return not (self.stopped[0] and self.stopped[1])

@@ -19,14 +19,31 @@ def readme_coo():
     return sp.coo_matrix((count.astype(np.float64), (user, item)), shape=(nusers, nitems))
 
 
-def uniform_coo(dimA, dimB, nnz, seed=1):
+class Triplets:
+    """COO triplets as plain arrays (row / col int64, data float64) with the few attributes of a SciPy COO matrix that
+    poismf_amd.api reads -- at 1e8 triplets building the SciPy object only copies and re-casts the index arrays."""
+
+    def __init__(self, row, col, data, shape):
+        self.row, self.col, self.data, self.shape = row, col, data, tuple(shape)
+        self.nnz = len(data)
+
+
+def uniform_triplets(dimA, dimB, nnz, seed=1):
     """C2-C4: uniform random positions, values 1 + floor(Gamma(1,1)); duplicates are summed later
     by the CSR/CSC conversion exactly as SciPy does for the reference."""
     rng = np.random.default_rng(seed)
     row = rng.integers(0, dimA, nnz, dtype=np.int64)
     col = rng.integers(0, dimB, nnz, dtype=np.int64)
-    val = 1.0 + np.floor(rng.gamma(1.0, 1.0, nnz))
-    return sp.coo_matrix((val, (row, col)), shape=(dimA, dimB))
+    val = rng.standard_gamma(1.0, nnz)
+    np.floor(val, out=val)
+    val += 1.0
+    return Triplets(row, col, val, (dimA, dimB))
+
+
+def uniform_coo(dimA, dimB, nnz, seed=1):
+    """The same triplets as a SciPy COO matrix."""
+    t = uniform_triplets(dimA, dimB, nnz, seed)
+    return sp.coo_matrix((t.data, (t.row, t.col)), shape=t.shape)
 
 
 def lastfm_like_coo(nusers=358858, nitems=160112, mean_deg=47, zipf_a=0.7, seed=1):

@@ -1,11 +1,12 @@
-"""bench.py's multi-GPU input builder: the per-rank CSR / CSC shards must tile the CSR / CSC of the stacked row
-blocks exactly (small sizes, CPU only)."""
+"""bench.py's multi-GPU planning on CPU: the per-rank row ranges tile the matrix, are identical on every rank (they are
+computed from the seeded triplets alone), balance the nonzeros, and the segments the sharded driver exchanges tile each
+rank's range exactly as the C session cuts them (poismf_hip_host.hip, finish_half)."""
 import importlib.util
 import os
 
 import numpy as np
-import scipy.sparse as sp
 
+from poismf_amd import dist as pdist
 from poismf_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,25 +19,33 @@ def _bench():
     return m
 
 
-def test_shards_tile_the_stacked_matrix():
+def test_plan_ranges_tile_and_balance():
     b = _bench()
-    world, rows, dimB, nnz = 4, 300, 240, 5000
-    blocks = [sp.csr_matrix(synth.uniform_coo(rows, dimB, nnz, seed=1 + r)) for r in range(world)]
-    full = sp.vstack(blocks).tocsr()
-    full.sum_duplicates(); full.sort_indices()
-    fcsc = full.tocsc(); fcsc.sort_indices()
-    total = 0
-    for rank in range(world):
-        csr, csc, dimA, dimB2, rA, rB = b.build_inputs(rank, world, False, BLOCK_ROWS=rows, DIMB=dimB, BLOCK_NNZ=nnz)
-        assert (dimA, dimB2) == (rows * world, dimB) and rA[rank] == (rank * rows, (rank + 1) * rows)
-        a0, a1 = rA[rank]
-        p = csr[2].astype(np.int64)
-        assert p[a0] == 0 and p[-1] == len(csr[0]) and np.all(p[:a0] == 0) and np.all(p[a1:] == p[a1])
-        ref = full[a0:a1]
-        assert np.array_equal(p[a0:a1 + 1], ref.indptr) and np.array_equal(csr[1], ref.indices) and np.array_equal(csr[0], ref.data)
-        c0, c1 = rB[rank]
-        q = csc[2].astype(np.int64)
-        refc = fcsc[:, c0:c1]
-        assert np.array_equal(q[c0:c1 + 1], refc.indptr) and np.array_equal(csc[1], refc.indices) and np.array_equal(csc[0], refc.data)
-        total += len(csr[0])
-    assert total == full.nnz
+    trip = synth.uniform_triplets(3000, 400, 60000, seed=1)
+    for world in (1, 2, 4, 8):
+        rA, rB = b.plan_ranges(trip, world)
+        for r, dim, idx in ((rA, 3000, trip.row), (rB, 400, trip.col)):
+            assert len(r) == world and r[0][0] == 0 and r[-1][1] == dim
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            counts = np.bincount(idx, minlength=dim)
+            loads = [int(counts[lo:hi].sum()) for lo, hi in r]
+            assert max(loads) <= 1.05 * len(idx) / world + counts.max()
+        assert (rA, rB) == b.plan_ranges(synth.uniform_triplets(3000, 400, 60000, seed=1), world)
+
+
+def test_choose_ranges_falls_back_to_nnz_balance_on_skewed_rows():
+    counts = np.r_[np.full(10, 1000), np.full(990, 1)]
+    eq = pdist.equal_ranges(1000, 4)
+    got = pdist.choose_ranges(counts, 4)
+    assert got != eq and got[0][1] < 10          # the heavy rows are split over ranks
+    assert pdist.choose_ranges(np.full(1000, 7), 4) == eq
+
+
+def test_segments_tile_a_range_like_the_session_does():
+    for rng in ((0, 10), (7, 1000), (5, 5), (125000, 250000)):
+        for nseg in (1, 2, 3, 4, 7):
+            segs = [pdist.segment_of(rng, j, nseg) for j in range(nseg)]
+            assert segs[0][0] == rng[0] and segs[-1][1] == rng[1]
+            assert all(segs[j][1] == segs[j + 1][0] for j in range(nseg - 1))
+            n = rng[1] - rng[0]
+            assert segs == [(rng[0] + n * j // nseg, rng[0] + n * (j + 1) // nseg) for j in range(nseg)]   # finish_half's cut
