@@ -47,11 +47,17 @@ class _Lib:
 class Oracle(_Lib):
     """This repo's C restatement."""
 
-    def __init__(self, is_float=False, blas_flavour=False):
+    def __init__(self, is_float=False, blas_flavour=False, fma_axpy=False):
         """blas_flavour=True loads oracle/_ref/liboracle_blas_*.so: the same restatement with its k-length
-        sums routed through the reference's own BLAS (only exists next to the compiled reference)."""
+        sums routed through the reference's own BLAS (only exists next to the compiled reference).
+        fma_axpy=True loads liboracle_fma_*.so: y += a x rounded once per element, as a BLAS with fused
+        multiply-add (and the GPU) computes it -- see vaxpy in poismf_oracle.c for why that matters in fp32 CG."""
         if blas_flavour:
             path = os.path.join(HERE, "_ref", "liboracle_blas_f.so" if is_float else "liboracle_blas_d.so")
+        elif fma_axpy:
+            path = os.path.join(HERE, "liboracle_fma_f.so" if is_float else "liboracle_fma_d.so")
+            if not os.path.exists(path):
+                build()
         else:
             path = os.path.join(HERE, "liboracle_f.so" if is_float else "liboracle_d.so")
             if not os.path.exists(path):

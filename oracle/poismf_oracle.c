@@ -73,10 +73,27 @@ static inline real_t vdot(int n, const real_t *x, const real_t *y)
     for (int i = 0; i < n; i++) s += x[i] * y[i];
     return s;
 }
+#ifdef ORACLE_FMA_AXPY
+/* Flavour liboracle_fma_*.so: y += a x with ONE rounding per element, as every BLAS with fused multiply-add does
+   (the SciPy OpenBLAS the compiled reference links on x86-64; the GPU kernels too).  It matters in the float build of
+   minimize_nonneg_cg: a step limited by max_step = -x_i / d_i lands coordinate i on x_i + step d_i, which is exactly 0
+   most of the time with two roundings but the division's rounding residual (~1e-9, above the 1e-15 snap of
+   ref src/nonnegcg.c:301-303) with one -- and a coordinate left at 1e-9 limits the NEXT step to nothing.  The compiled
+   reference shows exactly that behaviour on 1000-nonzero rows (scripts/probes/probe_cg32_long.py). */
+static inline void vaxpy(int n, real_t a, const real_t *x, real_t *y)
+{
+#ifdef USE_FLOAT
+    for (int i = 0; i < n; i++) y[i] = __builtin_fmaf(a, x[i], y[i]);
+#else
+    for (int i = 0; i < n; i++) y[i] = __builtin_fma(a, x[i], y[i]);
+#endif
+}
+#else
 static inline void vaxpy(int n, real_t a, const real_t *x, real_t *y)
 {
     for (int i = 0; i < n; i++) y[i] += a * x[i];
 }
+#endif
 static inline void vscal(int n, real_t a, real_t *x)
 {
     for (int i = 0; i < n; i++) x[i] *= a;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <csignal>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1083,15 +1084,28 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     p.l2_reg = l2_reg; p.l1_reg = l1_reg; p.w_mult = w_mult; p.step_size = step_size;
     p.method = method; p.limit_step = limit_step; p.maxupd = maxupd;
     p.early_stop = early_stop; p.reuse_prev = reuse_prev;
-    if (poismf_hip_session_create(&s, device, nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k, 0,
-                                  dimA, 0, dimB) ||
-        poismf_hip_session_set_factors(s, A, B) ||
-        run_alternation(s, p, numiter) ||
-        poismf_hip_session_get_factors(s, A, B)) {
+    // POISMF_HIP_VERBOSE=1: wall time of the phases of this call on stderr (development aid, scripts/time_abi.py)
+    static const bool verbose = getenv("POISMF_HIP_VERBOSE") != nullptr;
+    double t[5] = { 0, 0, 0, 0, 0 };
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6; };
+    t[0] = now();
+    bool bad = poismf_hip_session_create(&s, device, nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k, 0,
+                                         dimA, 0, dimB) != 0;
+    t[1] = now();
+    bad = bad || poismf_hip_session_set_factors(s, A, B);
+    t[2] = now();
+    bad = bad || run_alternation(s, p, numiter);
+    t[3] = now();
+    bad = bad || poismf_hip_session_get_factors(s, A, B);
+    t[4] = now();
+    if (bad) {
         fprintf(stderr, "Error: out of memory.\n");  // ref: :501
         ret_code = 1;
     }
     poismf_hip_session_destroy(s);
+    if (verbose)
+        fprintf(stderr, "run_poismf: session (upload X, sort rows) %.2f ms, factors up %.2f ms, %zu iterations %.2f ms, factors down %.2f ms, "
+                        "teardown %.2f ms\n", t[1] - t[0], t[2] - t[1], numiter, t[3] - t[2], t[4] - t[3], now() - t[4]);
     return sig.leave(ret_code, handle_interrupt);
 }
 

@@ -5,6 +5,28 @@ import scipy.sparse as sp
 from poismf_amd import harness, synth
 
 
+def checker(use_float, method="cg"):
+    """The oracle flavour GPU results are judged against.  PG: the plain flavour (literal left-to-right arithmetic) --
+    PG has no line search, agrees to 1e-12 / 1e-5 with any summation order, and its overflow cases (x / 0 = inf feeding
+    0 * inf = NaN, which the reference has no guard against) must come out entry for entry as IEEE arithmetic gives them,
+    not as a BLAS that skips `y += 0 * x` does.  CG / TNCG, preferred: oracle/_ref/liboracle_blas_*.so -- this repo's
+    restatement with its k-length sums routed through the BLAS the compiled reference links, which reproduces the
+    compiled reference BIT FOR BIT (tests/test_oracle_vs_ref.py) and travels to the GPU box with the snapshot.  The
+    solvers' line searches make discrete decisions on rounding-level differences: on BASELINE-sized rows the plain
+    left-to-right flavour ends some rows elsewhere than the reference does (C5, fp64 TNC, 29-nonzero item rows: line
+    search failure at f = 15484 where the reference converges at f = 12861 -- and the GPU lands on 12861.306156, the
+    reference's value, to 1e-10).  Fallback where _ref is absent: the flavour with fused multiply-add in y += a x."""
+    from oracle import bindings
+    if method == "pg":
+        return bindings.Oracle(use_float)
+    try:
+        if bindings.ref_available(use_float):
+            return bindings.Oracle(use_float, blas_flavour=True)
+    except OSError:
+        pass
+    return bindings.Oracle(use_float, fma_axpy=True)
+
+
 def dtype_of(use_float):
     return np.float32 if use_float else np.float64
 
