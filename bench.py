@@ -172,9 +172,28 @@ def roofline_block(job, res, traffic_key=None):
                     "nnz*(4+s+k*s) + 2*dimM*k*s + (dimM+1)*8 per half; traffic = fabric-side bytes per sweep from separate PMC passes"}
 
 
+def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
+    """Wall time of the drop-in run_poismf() itself -- host arrays in, host arrays out, set-up (upload, index narrowing and
+    row sort on the device) included: the PCIe-inclusive cost a caller of the reference's ABI sees.  Never `value`."""
+    l2, mu, _ = harness.auto_defaults(method, K)
+    maxupd = mu if maxupd is None else maxupd
+    A0, B0 = harness.initialize_matrices(dimA, dimB, K, use_float, 1)
+    t = {}
+    for numiter in (1, 1, 6):
+        A, B = A0.copy(), B0.copy()
+        t0 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            api._run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], A, B, method, True, l2, 0., 1., 1e-7, numiter, maxupd,
+                            False, True, True, 1)
+        t[numiter] = (time.perf_counter() - t0) * 1e3
+    return {"abi_ms_first_iter": t[1], "abi_ms_per_extra_iter": (t[6] - t[1]) / 5.0,
+            "note": f"run_poismf(method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}) on the workload matrix through "
+                    "ctypes, second call of the process (the first also pays device initialisation)"}
+
+
 def cpu_baseline(trip, method, use_float, maxupd):
     """The compiled reference (oracle/_ref) on this box's host cores, same matrix: steady-state seconds per sweep =
-    t(2 outer iterations) - t(1 outer iteration)."""
+    t(2 outer iterations) - t(1 outer iteration).  Returns (cpu_baseline block, abi block)."""
     from oracle import bindings
     try:
         import psutil
@@ -206,10 +225,11 @@ def cpu_baseline(trip, method, use_float, maxupd):
                 break
     except OSError:
         pass
+    abi = abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd)
     return {"value": nnz / dt, "unit": "nnz/s per full sweep", "cores": int(cores), "kind": kind,
             "sample": f"the whole workload matrix ({nnz} nnz), method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}: "
                       f"run_poismf with 2 outer iterations ({times[1]:.2f} s) minus 1 outer iteration ({times[0]:.2f} s) = one steady-state "
-                      f"sweep, OpenMP threads={cores} on {cpu}"}
+                      f"sweep, OpenMP threads={cores} on {cpu}"}, abi
 
 
 def main():
@@ -311,7 +331,8 @@ def main():
         final_line = out
     if single and not a.no_cpu and rank == 0:
         job.close()
-        final_line["cpu_baseline"] = cpu_baseline(trip, a.method, use_float, a.maxupd)
+        final_line["cpu_baseline"], abi = cpu_baseline(trip, a.method, use_float, a.maxupd)
+        final_line.setdefault("extra", {})["run_poismf_abi"] = abi
     else:
         job.close()
     if dist.is_initialized():

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/poismf_hip.h"
+#include "devmem.hpp"
 
 namespace {
 
@@ -94,17 +95,17 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
     size_t* d_count = nullptr;
     void* tmp = nullptr;
     auto cleanup = [&]() {
-        if (keys_a) (void)hipFree(keys_a);
-        if (keys_b) (void)hipFree(keys_b);
-        if (vals_b) (void)hipFree(vals_b);
-        if (d_count) (void)hipFree(d_count);
-        if (tmp) (void)hipFree(tmp);
+        pmf_free(keys_a, stream);
+        pmf_free(keys_b, stream);
+        pmf_free(vals_b, stream);
+        pmf_free(d_count, stream);
+        pmf_free(tmp, stream);
     };
 #define TRY_OR_CLEAN(expr) do { if ((expr) != hipSuccess) { fprintf(stderr, "poismf_hip: %s failed\n", #expr); cleanup(); return 1; } } while (0)
-    TRY_OR_CLEAN(hipMalloc(&keys_a, sizeof(unsigned long long) * n));
-    TRY_OR_CLEAN(hipMalloc(&keys_b, sizeof(unsigned long long) * n));
-    TRY_OR_CLEAN(hipMalloc(&vals_b, sizeof(real_t) * n));
-    TRY_OR_CLEAN(hipMalloc(&d_count, sizeof(size_t)));
+    TRY_OR_CLEAN(pmf_alloc(&keys_a, sizeof(unsigned long long) * n, stream));
+    TRY_OR_CLEAN(pmf_alloc(&keys_b, sizeof(unsigned long long) * n, stream));
+    TRY_OR_CLEAN(pmf_alloc(&vals_b, sizeof(real_t) * n, stream));
+    TRY_OR_CLEAN(pmf_alloc(&d_count, sizeof(size_t), stream));
     const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(pack_keys, dim3(grid), dim3(256), 0, stream, d_major, d_minor, n, (unsigned)major_begin, (unsigned)major_end, keys_a);
 
@@ -113,15 +114,15 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
     const unsigned end_bit = (unsigned)(32 + bits_for(dim_major + 1));
     size_t tmp_bytes = 0;
     TRY_OR_CLEAN(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, d_val, vals_b, n, 0u, end_bit, stream));
-    TRY_OR_CLEAN(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    TRY_OR_CLEAN(pmf_alloc(&tmp, tmp_bytes ? tmp_bytes : 16, stream));
     TRY_OR_CLEAN(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, d_val, vals_b, n, 0u, end_bit, stream));
-    (void)hipFree(tmp); tmp = nullptr;
+    pmf_free(tmp, stream); tmp = nullptr;
 
     // equal keys -> one entry holding the sum (keys_a is reused for the unique keys)
     size_t tmp2 = 0;
     TRY_OR_CLEAN(rocprim::reduce_by_key(nullptr, tmp2, keys_b, vals_b, (unsigned int)n, keys_a, out_val, d_count,
                                         rocprim::plus<real_t>(), rocprim::equal_to<unsigned long long>(), stream));
-    TRY_OR_CLEAN(hipMalloc(&tmp, tmp2 ? tmp2 : 16));
+    TRY_OR_CLEAN(pmf_alloc(&tmp, tmp2 ? tmp2 : 16, stream));
     TRY_OR_CLEAN(rocprim::reduce_by_key(tmp, tmp2, keys_b, vals_b, (unsigned int)n, keys_a, out_val, d_count,
                                         rocprim::plus<real_t>(), rocprim::equal_to<unsigned long long>(), stream));
     size_t uniq = 0;
@@ -155,18 +156,17 @@ int poismf_hip_device_sort_rows(const unsigned long long* d_indptr, size_t nloc,
     unsigned *len = nullptr, *ids = nullptr;
     void* tmp = nullptr;
     auto cleanup = [&]() {
-        if (len) (void)hipFree(len);
-        if (ids) (void)hipFree(ids);
-        if (tmp) (void)hipFree(tmp);
+        pmf_free(len, stream);
+        pmf_free(ids, stream);
+        pmf_free(tmp, stream);
     };
-    if (hipMalloc(&len, sizeof(unsigned) * nloc) != hipSuccess || hipMalloc(&ids, sizeof(unsigned) * nloc) != hipSuccess) { cleanup(); return 1; }
+    if (pmf_alloc(&len, sizeof(unsigned) * nloc, stream) != hipSuccess || pmf_alloc(&ids, sizeof(unsigned) * nloc, stream) != hipSuccess) { cleanup(); return 1; }
     const unsigned grid = (unsigned)std::min<size_t>((nloc + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(row_len_kernel, dim3(grid), dim3(256), 0, stream, d_indptr, nloc, base, len, ids);
     size_t bytes = 0;
     if (rocprim::radix_sort_pairs_desc(nullptr, bytes, len, d_len_sorted, ids, d_perm, nloc, 0u, 32u, stream) != hipSuccess ||
-        hipMalloc(&tmp, bytes ? bytes : 16) != hipSuccess ||
-        rocprim::radix_sort_pairs_desc(tmp, bytes, len, d_len_sorted, ids, d_perm, nloc, 0u, 32u, stream) != hipSuccess ||
-        hipStreamSynchronize(stream) != hipSuccess) { cleanup(); return 1; }
+        pmf_alloc(&tmp, bytes ? bytes : 16, stream) != hipSuccess ||
+        rocprim::radix_sort_pairs_desc(tmp, bytes, len, d_len_sorted, ids, d_perm, nloc, 0u, 32u, stream) != hipSuccess) { cleanup(); return 1; }
     cleanup();
     return 0;
 }

@@ -9,6 +9,7 @@
 
 #include "../../include/poismf_hip.h"
 #include "row_eval.hpp"
+#include "devmem.hpp"
 
 using namespace pmf;
 

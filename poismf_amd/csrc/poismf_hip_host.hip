@@ -224,14 +224,14 @@ struct poismf_hip_session {
 
 namespace {
 
-void free_half(Half& h)
+void free_half(Half& h, hipStream_t stream)
 {
-    if (h.d_indptr) (void)hipFree(h.d_indptr);
-    if (h.d_indices) (void)hipFree(h.d_indices);
-    if (h.d_values) (void)hipFree(h.d_values);
-    if (h.d_perm) (void)hipFree(h.d_perm);
-    if (h.d_desc) (void)hipFree(h.d_desc);
-    if (h.d_eval_rows) (void)hipFree(h.d_eval_rows);
+    pmf_free(h.d_indptr, stream);
+    pmf_free(h.d_indices, stream);
+    pmf_free(h.d_values, stream);
+    pmf_free(h.d_perm, stream);
+    pmf_free(h.d_desc, stream);
+    pmf_free(h.d_eval_rows, stream);
     h = Half();
 }
 
@@ -272,23 +272,23 @@ int finish_half(Half& h, hipStream_t stream, int nseg = 1)
 {
     const size_t nloc = h.row_end - h.row_begin;
     unsigned* d_len = nullptr;
-    if (h.d_perm == nullptr) HIP_TRY(hipMalloc(&h.d_perm, sizeof(unsigned) * (nloc ? nloc : 1)));
-    if (h.d_desc == nullptr) HIP_TRY(hipMalloc(&h.d_desc, sizeof(RowDesc) * (nloc ? nloc : 1)));
+    if (h.d_perm == nullptr) HIP_TRY(pmf_alloc(&h.d_perm, sizeof(unsigned) * (nloc ? nloc : 1), stream));
+    if (h.d_desc == nullptr) HIP_TRY(pmf_alloc(&h.d_desc, sizeof(RowDesc) * (nloc ? nloc : 1), stream));
     h.segs.clear();
     nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(nseg, 1), std::max<size_t>(nloc, 1)));
     if (nloc == 0) { h.segs.push_back({ 0u, 0u, {} }); return 0; }
-    HIP_TRY(hipMalloc(&d_len, sizeof(unsigned) * nloc));
+    HIP_TRY(pmf_alloc(&d_len, sizeof(unsigned) * nloc, stream));
     for (int j = 0; j < nseg; j++) {
         const size_t lo = nloc * (size_t)j / (size_t)nseg, hi = nloc * (size_t)(j + 1) / (size_t)nseg;   // == dist.segment_of
         h.segs.push_back({ (unsigned)lo, (unsigned)hi, {} });
-        if (hi > lo && poismf_hip_device_sort_rows(h.d_indptr + lo, hi - lo, (unsigned)lo, h.d_perm + lo, d_len + lo, stream)) { (void)hipFree(d_len); return 1; }
+        if (hi > lo && poismf_hip_device_sort_rows(h.d_indptr + lo, hi - lo, (unsigned)lo, h.d_perm + lo, d_len + lo, stream)) { pmf_free(d_len, stream); return 1; }
     }
     const unsigned grid = (unsigned)std::min<size_t>((nloc + 255) / 256, 2048);
     hipLaunchKernelGGL(row_desc_kernel, dim3(grid), dim3(256), 0, stream, h.d_indptr, h.d_perm, nloc, h.d_desc);
     std::vector<unsigned> len(nloc);
     hipError_t e = hipMemcpyAsync(len.data(), d_len, sizeof(unsigned) * nloc, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(d_len);
+    pmf_free(d_len, stream);
     HIP_TRY(e);
     for (auto& sg : h.segs) {
         for (size_t i = sg.row_lo; i < sg.row_hi; i++) {
@@ -310,9 +310,9 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     const size_t nloc = r1 - r0;
     const size_t base = indptr[r0];
     h.nnz = indptr[r1] - base;
-    HIP_TRY(hipMalloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1)));
-    HIP_TRY(hipMalloc(&h.d_indices, sizeof(unsigned) * (h.nnz ? h.nnz : 1)));
-    HIP_TRY(hipMalloc(&h.d_values, sizeof(real_t) * (h.nnz ? h.nnz : 1)));
+    HIP_TRY(pmf_alloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1), stream));
+    HIP_TRY(pmf_alloc(&h.d_indices, sizeof(unsigned) * (h.nnz ? h.nnz : 1), stream));
+    HIP_TRY(pmf_alloc(&h.d_values, sizeof(real_t) * (h.nnz ? h.nnz : 1), stream));
     HIP_TRY(hipMemcpyAsync(h.d_indptr, indptr + r0, sizeof(unsigned long long) * (nloc + 1), hipMemcpyHostToDevice, stream));
     if (base != 0) {
         hipLaunchKernelGGL(rebase_indptr_kernel, dim3((unsigned)std::min<size_t>((nloc + 256) / 256, 2048)), dim3(256), 0, stream, h.d_indptr, nloc + 1,
@@ -320,12 +320,12 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     }
     if (h.nnz) {
         unsigned long long* d_wide = nullptr;
-        HIP_TRY(hipMalloc(&d_wide, sizeof(unsigned long long) * h.nnz));
+        HIP_TRY(pmf_alloc(&d_wide, sizeof(unsigned long long) * h.nnz, stream));
         hipError_t e = hipMemcpyAsync(d_wide, indices + base, sizeof(unsigned long long) * h.nnz, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess && poismf_hip_device_narrow(d_wide, h.nnz, h.d_indices, stream)) e = hipErrorUnknown;
         if (e == hipSuccess) e = hipMemcpyAsync(h.d_values, val + base, sizeof(real_t) * h.nnz, hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(d_wide);
+        pmf_free(d_wide, stream);
         HIP_TRY(e);
     }
     return finish_half(h, stream);
@@ -423,6 +423,29 @@ int colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t s
 
 extern "C" {
 
+// Streams are recycled across sessions: creating one costs 7.5 ms on this stack (scripts/probes/h2d_probe.hip) -- with two
+// per run_poismf call that was most of the call's set-up time on config C2.  Idle streams wait here, per device.
+static std::mutex g_stream_mutex;
+static std::vector<hipStream_t> g_idle_streams[64];
+static int cached_stream(int device, hipStream_t* out)
+{
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(g_stream_mutex);
+        auto& v = g_idle_streams[device];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return 0; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking) != hipSuccess;
+}
+static void release_stream(int device, hipStream_t st)
+{
+    (void)hipStreamSynchronize(st);
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(g_stream_mutex);
+        if (g_idle_streams[device].size() < 8) { g_idle_streams[device].push_back(st); return; }
+    }
+    (void)hipStreamDestroy(st);
+}
+
 // Everything of a session except the two halves of X: streams, the replicated factors (+ their line-padded gather
 // copies), column-sum scratch.  On failure the partly built session is destroyed and nullptr returned.
 static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, size_t dimB, size_t k)
@@ -442,15 +465,15 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     s->stream = (hipStream_t)stream;
     auto fail = [&]() -> poismf_hip_session* { poismf_hip_session_destroy(s); return nullptr; };
     if (s->stream == nullptr) {  // no stream given: the session owns a non-blocking stream (NOT the legacy default stream)
-        if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return nullptr; }
+        if (cached_stream(device, &s->stream)) { delete s; return nullptr; }
         s->owns_stream = true;
     }
     s->dimA = dimA; s->dimB = dimB; s->k = k;
     // behind each factor: one all-zero row (the register engine points the unused steps of a row at it) + 16 B so that
     // the last 16-byte slot of the last row stays in bounds
     const size_t slack = k * sizeof(real_t) + 16;
-    if (hipMalloc(&s->dA, dimA * k * sizeof(real_t) + slack) != hipSuccess) return fail();
-    if (hipMalloc(&s->dB, dimB * k * sizeof(real_t) + slack) != hipSuccess) return fail();
+    if (pmf_alloc(&s->dA, dimA * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->dB, dimB * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (hipMemsetAsync(s->dA, 0, dimA * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (hipMemsetAsync(s->dB, 0, dimB * k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     {
@@ -466,17 +489,17 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
         if (padb != rowb) {
             s->ld = padb / sizeof(real_t);
             const size_t pslack = padb + 16;
-            if (hipMalloc(&s->dAp, dimA * padb + pslack) != hipSuccess) return fail();
-            if (hipMalloc(&s->dBp, dimB * padb + pslack) != hipSuccess) return fail();
+            if (pmf_alloc(&s->dAp, dimA * padb + pslack, s->stream) != hipSuccess) return fail();
+            if (pmf_alloc(&s->dBp, dimB * padb + pslack, s->stream) != hipSuccess) return fail();
             if (hipMemsetAsync(s->dAp, 0, dimA * padb + pslack, s->stream) != hipSuccess) return fail();
             if (hipMemsetAsync(s->dBp, 0, dimB * padb + pslack, s->stream) != hipSuccess) return fail();
         }
     }
-    if (hipMalloc(&s->d_bsum, k * sizeof(real_t) + slack) != hipSuccess) return fail();
-    if (hipMalloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t)) != hipSuccess) return fail();
-    if (hipMalloc(&s->d_counter, sizeof(unsigned)) != hipSuccess) return fail();
-    if (hipMalloc(&s->d_queue, sizeof(unsigned) * MAX_LAUNCHES) != hipSuccess) return fail();
-    if (hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_bsum, k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t), s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * MAX_LAUNCHES, s->stream) != hipSuccess) return fail();
+    if (cached_stream(device, &s->aux_stream)) return fail();
     if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) return fail();
     if (hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail();
     return s;
@@ -508,24 +531,24 @@ static int half_from_device_coo(Half& h, hipStream_t stream, const unsigned* d_m
     const size_t nloc = m1 - m0;
     unsigned* t_idx = nullptr;
     real_t* t_val = nullptr;
-    HIP_TRY(hipMalloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1)));
-    hipError_t e = hipMalloc(&t_idx, sizeof(unsigned) * n);
-    if (e == hipSuccess) e = hipMalloc(&t_val, sizeof(real_t) * n);
+    HIP_TRY(pmf_alloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1), stream));
+    hipError_t e = pmf_alloc(&t_idx, sizeof(unsigned) * n, stream);
+    if (e == hipSuccess) e = pmf_alloc(&t_val, sizeof(real_t) * n, stream);
     size_t uniq = 0;
     int rc = e != hipSuccess;
     if (!rc) rc = poismf_hip_device_coo_to_cs(d_major, d_minor, d_val, n, m0, m1, t_idx, t_val, h.d_indptr, &uniq, stream);
     if (!rc) {
         h.nnz = uniq;
         // the conversion's outputs have room for all n triplets; the session keeps exactly sized copies
-        if (hipMalloc(&h.d_indices, sizeof(unsigned) * (uniq ? uniq : 1)) != hipSuccess ||
-            hipMalloc(&h.d_values, sizeof(real_t) * (uniq ? uniq : 1)) != hipSuccess ||
+        if (pmf_alloc(&h.d_indices, sizeof(unsigned) * (uniq ? uniq : 1), stream) != hipSuccess ||
+            pmf_alloc(&h.d_values, sizeof(real_t) * (uniq ? uniq : 1), stream) != hipSuccess ||
             hipMemcpyAsync(h.d_indices, t_idx, sizeof(unsigned) * uniq, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
             hipMemcpyAsync(h.d_values, t_val, sizeof(real_t) * uniq, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess)
             rc = 1;
     }
-    if (t_idx) (void)hipFree(t_idx);
-    if (t_val) (void)hipFree(t_val);
+    pmf_free(t_idx, stream);
+    pmf_free(t_val, stream);
     return rc ? 1 : finish_half(h, stream);
 }
 
@@ -542,8 +565,8 @@ int poismf_hip_session_create_coo(poismf_hip_session** out, int device, void* st
     real_t* d_val = nullptr;
     int rc = 1;
     do {
-        if (hipMalloc(&d_row, sizeof(unsigned) * n) != hipSuccess || hipMalloc(&d_col, sizeof(unsigned) * n) != hipSuccess ||
-            hipMalloc(&d_val, sizeof(real_t) * n) != hipSuccess)
+        if (pmf_alloc(&d_row, sizeof(unsigned) * n, s->stream) != hipSuccess || pmf_alloc(&d_col, sizeof(unsigned) * n, s->stream) != hipSuccess ||
+            pmf_alloc(&d_val, sizeof(real_t) * n, s->stream) != hipSuccess)
             break;
         {
             std::vector<unsigned> h32;
@@ -559,9 +582,9 @@ int poismf_hip_session_create_coo(poismf_hip_session** out, int device, void* st
         if (half_from_device_coo(s->half[1], s->stream, d_row, d_col, d_val, n, dimA, dimB, rowA_begin, rowA_end)) break;
         rc = 0;
     } while (0);
-    if (d_row) (void)hipFree(d_row);
-    if (d_col) (void)hipFree(d_col);
-    if (d_val) (void)hipFree(d_val);
+    pmf_free(d_row, s->stream);
+    pmf_free(d_col, s->stream);
+    pmf_free(d_val, s->stream);
     if (rc) { poismf_hip_session_destroy(s); return 1; }
     *out = s;
     return 0;
@@ -577,18 +600,20 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     s->prof.clear();
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-    if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
-    if (s->owns_stream) (void)hipStreamDestroy(s->stream);
-    free_half(s->half[0]);
-    free_half(s->half[1]);
-    if (s->dA) (void)hipFree(s->dA);
-    if (s->dB) (void)hipFree(s->dB);
-    if (s->dAp) (void)hipFree(s->dAp);
-    if (s->dBp) (void)hipFree(s->dBp);
-    if (s->d_bsum) (void)hipFree(s->d_bsum);
-    if (s->d_partial) (void)hipFree(s->d_partial);
-    if (s->d_counter) (void)hipFree(s->d_counter);
-    if (s->d_queue) (void)hipFree(s->d_queue);
+    const hipStream_t own = s->owns_stream ? s->stream : nullptr, aux = s->aux_stream;
+    free_half(s->half[0], s->stream);
+    free_half(s->half[1], s->stream);
+    pmf_free(s->dA, s->stream);
+    pmf_free(s->dB, s->stream);
+    pmf_free(s->dAp, s->stream);
+    pmf_free(s->dBp, s->stream);
+    pmf_free(s->d_bsum, s->stream);
+    pmf_free(s->d_partial, s->stream);
+    pmf_free(s->d_counter, s->stream);
+    pmf_free(s->d_queue, s->stream);
+    (void)hipStreamSynchronize(s->stream);   // the stream-ordered frees have run
+    if (aux) release_stream(s->device, aux);
+    if (own) release_stream(s->device, own);
     delete s;
 }
 
@@ -654,7 +679,7 @@ void poismf_hip_session_profile(poismf_hip_session* s, int enable)
     s->profiling = enable != 0;
     for (Half& h : s->half) {
         const size_t n = h.row_end - h.row_begin;
-        if (s->profiling && h.d_eval_rows == nullptr && n > 0 && hipMalloc(&h.d_eval_rows, sizeof(unsigned) * n) != hipSuccess) h.d_eval_rows = nullptr;
+        if (s->profiling && h.d_eval_rows == nullptr && n > 0 && pmf_alloc(&h.d_eval_rows, sizeof(unsigned) * n, s->stream) != hipSuccess) h.d_eval_rows = nullptr;
         if (h.d_eval_rows != nullptr) (void)hipMemsetAsync(h.d_eval_rows, 0, sizeof(unsigned) * n, s->stream);
     }
 }
