@@ -72,6 +72,10 @@ constexpr int REG_JG = WAVE / REG_G;
 // tile sizes in nonzeros with an instantiated kernel (S = nonzeros / REG_JG steps)
 #define PMF_REG_SIZES(X) X(16) X(32) X(48) X(64) X(80) X(96) X(112) X(128) X(144) X(160)
 constexpr int REG_NNZ_MAX = 160;
+// 16-byte slots per lane: factor rows of up to REG_G slots take one, doubles with up to 2 REG_G slots (k = 50 fp64: 25) take
+// two -- one wave per row only, at one wave per SIMD (the tile alone is 8 S registers); 0 = not a register-engine row.
+constexpr int REG_NS_MAX = (sizeof(real_t) == 8 && REG_G == 16) ? 2 : (REG_G == 8 ? 2 : 1);
+inline int reg_slots_per_lane(size_t s_load) { return s_load <= (size_t)REG_G ? 1 : (s_load <= (size_t)REG_G * REG_NS_MAX ? 2 : 0); }
 int reg_steps_for(unsigned max_nnz)
 {
 #define X(NZ) if ((unsigned)(NZ) >= max_nnz) return (NZ) / REG_JG;
@@ -98,9 +102,20 @@ unsigned regw_wave_nnz_max(int method)
     return (unsigned)(method == POISMF_PG ? REGW_WAVE_NNZ_MAX_PG : method == POISMF_CG ? REGW_WAVE_NNZ_MAX_CG : REGW_WAVE_NNZ_MAX_TNCG);
 }
 unsigned regw_nnz_max(int method) { return (unsigned)REG_NW_MAX * regw_wave_nnz_max(method); }
-// the fewest waves (2, 4, 8) whose shares of a row of max_nnz nonzeros fit
+// Sixteen waves per row (one 1024-thread workgroup, four waves per SIMD, <= 128 registers each: shares of <= 64
+// nonzeros) for rows of 513 .. 1024 nonzeros: measured and NOT adopted (-DPMF_REGW16=1 builds it).  One such row occupies
+// a CU either way and a SIMD gets four instruction streams instead of two, but the per-pass fixed work of a wave (point
+// update, group combine, reading 16 partial gradients, a 16-wave barrier) is paid twice as often: C4 matrix, PG(10), B half
+// 7.9 ms with eight waves per row, 13.9 ms with sixteen.
+#ifndef PMF_REGW16
+#define PMF_REGW16 0
+#endif
+constexpr int REGW16_WAVE_NNZ = 64;
+inline bool regw16_method(int method) { return PMF_REGW16 && method == POISMF_PG; }
+// the fewest waves (2, 4, 8) whose shares of a row of max_nnz nonzeros fit; 16 where that pays (see above)
 int regw_waves_for(unsigned max_nnz, int method)
 {
+    if (regw16_method(method) && max_nnz > 8u * REGW16_WAVE_NNZ && max_nnz <= 16u * REGW16_WAVE_NNZ) return 16;
     for (int nw : { 2, 4, 8 })
         if (max_nnz <= (unsigned)nw * regw_wave_nnz_max(method)) return nw;
     return 0;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(reg_waves(
 constexpr int regw_waves(int tile_regs, int method, int nw)
 {
     const int w = reg_waves(tile_regs, method);
-    return nw >= 8 && w < 2 ? 2 : w;   // eight waves are two per SIMD
+    return nw >= 16 && w < 4 ? 4 : (nw >= 8 && w < 2 ? 2 : w);   // eight waves are two per SIMD, sixteen four
 }
 template <class T, int METHOD, int S, int G, int NS, int NW>
 __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(regw_waves(4 * S * NS, METHOD, NW)))) void half_sweep_regw_kernel(const HalfArgs<T> a)
@@ -311,10 +311,10 @@ template <int S, int NS> int launch_reg_method(hipStream_t stream, int method, c
             if constexpr (tu_has(K_PG)) return launch_reg<K_PG, S, NS>(stream, a, grid_mult);
             else return 1;
         case POISMF_CG:
-            if constexpr (tu_has(K_CG) && S * REG_JG <= REG_NNZ_MAX_CG) return launch_reg<K_CG, S, NS>(stream, a, grid_mult);
+            if constexpr (tu_has(K_CG) && S * REG_JG <= REG_NNZ_MAX_CG && (NS == 1 || S * REG_JG <= 144)) return launch_reg<K_CG, S, NS>(stream, a, grid_mult);
             else return 1;
         default:
-            if constexpr (tu_has(K_TNCG) && S * REG_JG <= REG_NNZ_MAX_TNCG) return launch_reg<K_TNCG, S, NS>(stream, a, grid_mult);
+            if constexpr (tu_has(K_TNCG) && S * REG_JG <= REG_NNZ_MAX_TNCG && (NS == 1 || S * REG_JG <= 112)) return launch_reg<K_TNCG, S, NS>(stream, a, grid_mult);
             else return 1;
     }
 }
@@ -339,15 +339,16 @@ template <int METHOD, int S, int NS, int NW> int launch_regw(hipStream_t stream,
 template <int S, int NS, int NW> int launch_regw_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (S * REG_JG < 32) return 1;
+    else if constexpr (NW == 16 && (S * REG_JG > REGW16_WAVE_NNZ || NS != 1)) return 1;
     else switch (method) {
         case POISMF_PG:
             if constexpr (tu_has(K_PG)) return launch_regw<K_PG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
         case POISMF_CG:
-            if constexpr (tu_has(K_CG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_CG) return launch_regw<K_CG, S, NS, NW>(stream, a, grid_mult);
+            if constexpr (tu_has(K_CG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_CG && NW <= 8) return launch_regw<K_CG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
         default:
-            if constexpr (tu_has(K_TNCG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG) return launch_regw<K_TNCG, S, NS, NW>(stream, a, grid_mult);
+            if constexpr (tu_has(K_TNCG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG && NW <= 8) return launch_regw<K_TNCG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
     }
 }
@@ -367,6 +368,9 @@ template <int NS> int launch_regw_steps(hipStream_t stream, int nw, int S, int m
         case 2: return launch_regw_steps_nw<NS, 2>(stream, S, method, a, grid_mult);
         case 4: return launch_regw_steps_nw<NS, 4>(stream, S, method, a, grid_mult);
         case 8: return launch_regw_steps_nw<NS, 8>(stream, S, method, a, grid_mult);
+        case 16:
+            if constexpr (PMF_REGW16) return launch_regw_steps_nw<NS, 16>(stream, S, method, a, grid_mult);
+            else return 1;
     }
     return 1;
 }
@@ -391,7 +395,7 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
             if constexpr (REG_G == 16) rc = launch_regw_steps<1>(o.main_stream, o.nw, o.reg_S, method, a, o.grid_mult);
             else rc = o.s_load <= REG_G ? launch_regw_steps<1>(o.main_stream, o.nw, o.reg_S, method, a, o.grid_mult)
                                         : launch_regw_steps<2>(o.main_stream, o.nw, o.reg_S, method, a, o.grid_mult);
-        } else if constexpr (REG_G == 16) rc = launch_reg_steps<1>(o.bin_stream, o.reg_S, method, a, o.grid_mult);
+        } else if constexpr (REG_NS_MAX == 1) rc = launch_reg_steps<1>(o.bin_stream, o.reg_S, method, a, o.grid_mult);
         else rc = o.s_load <= REG_G ? launch_reg_steps<1>(o.bin_stream, o.reg_S, method, a, o.grid_mult)
                                     : launch_reg_steps<2>(o.bin_stream, o.reg_S, method, a, o.grid_mult);
         return rc;

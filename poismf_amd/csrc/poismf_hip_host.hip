@@ -811,9 +811,16 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; };
     std::vector<Launch> launches;
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
-    // register engine: factor rows of at most 16 slots, and 24-bit row ids / 32-bit byte offsets into the factor
-    const bool reg_ok = !no_reg && (s->k * sizeof(real_t) + 15) / 16 <= 16 &&
+    // register engine: factor rows of at most 16 slots (32 for doubles, two slots per lane), and 24-bit row ids / 32-bit
+    // byte offsets into the factor
+    const int reg_ns = reg_slots_per_lane((s->k * sizeof(real_t) + 15) / 16);
+    const bool reg_ok = !no_reg && reg_ns > 0 &&
                         dimF < ((size_t)1 << 24) && (dimF + 1) * ldF * sizeof(real_t) + 16 < ((size_t)1 << 32);
+    // two slots per lane: single-wave rows only, and TNC's ~21 k-vectors leave room for 112 nonzeros of tile
+    const bool regw_ok = reg_ok && (reg_ns == 1 || REG_G == 8);
+    // (kernel-resource-usage: CG with 40 steps of two slots spills 360 bytes per lane even at one wave per SIMD, 36 steps 60)
+    const unsigned reg_max = reg_ns == 2 && REG_G == 16 ? (p->method == POISMF_TNCG ? 112u : p->method == POISMF_CG ? 144u : reg_nnz_max(p->method))
+                                                        : reg_nnz_max(p->method);
     static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
     if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
@@ -823,7 +830,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     for (const Bin& b : bins) {
         TileGeom g = plan_geom(s->k, b.cls, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
-        if (reg_ok && b.cls <= reg_nnz_max(p->method)) {
+        if (reg_ok && b.cls <= reg_max) {
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
             // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
             const int S = reg_steps_for(b.max_nnz);
@@ -834,7 +841,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 launches.push_back({ b.begin, b.count, g, 1, S });
             continue;
         }
-        if (reg_ok && b.cls <= regw_nnz_max(p->method)) {
+        if (regw_ok && b.cls <= regw_nnz_max(p->method)) {
             // medium rows: 2, 4 or 8 waves share a row, each keeps its part of the tile in registers
             const int nw = regw_waves_for(b.cls, p->method);
             const int S = regw_steps_for(b.max_nnz, nw);

@@ -141,7 +141,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     static constexpr int NB = (S + G - 1) / G;    // batches of G steps = 64 nonzeros
     static constexpr int NW = NW_;
     static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
-    static constexpr int KP = 16 * SN;            // elements of a (padded) k-vector in the cross-wave scratch
+    static constexpr int KP = G * NS * SN;        // elements of a (padded) k-vector in the cross-wave scratch
     static constexpr int RED_BYTES = NW_ * KP * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16);   // one set of cross-wave scratch
     static constexpr int SMEM_BYTES = NW_ > 1 ? 2 * RED_BYTES + 16 : 0;
     static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
@@ -165,10 +165,14 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
     int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
     unsigned* ticket_word;
-    // interface parity with RowEval (the cached line search is for streamed rows only)
+    // Cached line search (solvers.hpp, cg_row_cached): the predictions p_j = F_j . x and q_j = F_j . d of the nonzero each
+    // lane finishes stay in registers (pv / qv, one per batch); pbuf / qbuf are only tags that tell eval() which of the
+    // two a pass is to keep.  Used by the fp64 single-wave kernels (pq_cap > 0): one wave per SIMD, where an Armijo trial
+    // as two logs instead of a pass over the tile is what shortens the row (C3 CG fp64 A half: 37.3 -> see DESIGN.md).
     int pq_cap;
     T* pbuf;
     T* qbuf;
+    T pv[NB], qv[NB];
 
     __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
@@ -191,7 +195,8 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
                 act[n * SN + e] = q * SN + e < k;
             }
         }
-        pq_cap = 0; pbuf = nullptr; qbuf = nullptr;
+        pq_cap = (sizeof(T) == 8 && NW == 1) ? 0x7fffffff : 0;
+        pbuf = (T*)(size_t)16; qbuf = (T*)(size_t)32;   // tags, never dereferenced
     }
 
     // ---- k-length vector helpers (the slot layout of RowEval, with G = 8 as well) ----------------------
@@ -301,29 +306,34 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
                     SA v;
 #pragma unroll
                     for (int e = 0; e < SN; e++) v.v[e] = tot[n * SN + e];
-                    red_slots[wid * 16 + g + G * n] = v;
+                    red_slots[wid * (G * NS) + g + G * n] = v;
                 }
             }
             if (lane == 0) red_l[wid] = lsum;
             __syncthreads();
-            SA part[NW][NS];
-            double lp[NW];
-#pragma unroll
-            for (int w = 0; w < NW; w++) {        // all reads in flight, then the sums in wave order
-                lp[w] = red_l[w];
-#pragma unroll
-                for (int n = 0; n < NS; n++) part[w][n] = red_slots[w * 16 + g + G * n];
-            }
+            // reads of up to eight waves' partials in flight at a time, sums in wave order
             lsum = 0.0;
 #pragma unroll
             for (int i = 0; i < NC; i++) tot[i] = (T)0;
+            constexpr int WB = NW < 8 ? NW : 8;
 #pragma unroll
-            for (int w = 0; w < NW; w++) {
-                lsum += lp[w];
+            for (int w0 = 0; w0 < NW; w0 += WB) {
+                SA part[WB][NS];
+                double lp[WB];
 #pragma unroll
-                for (int n = 0; n < NS; n++) {
+                for (int w = 0; w < WB; w++) {
+                    lp[w] = red_l[w0 + w];
 #pragma unroll
-                    for (int e = 0; e < SN; e++) tot[n * SN + e] += act[n * SN + e] ? part[w][n].v[e] : (T)0;
+                    for (int n = 0; n < NS; n++) part[w][n] = red_slots[(w0 + w) * (G * NS) + g + G * n];
+                }
+#pragma unroll
+                for (int w = 0; w < WB; w++) {
+                    lsum += lp[w];
+#pragma unroll
+                    for (int n = 0; n < NS; n++) {
+#pragma unroll
+                        for (int e = 0; e < SN; e++) tot[n * SN + e] += act[n * SN + e] ? part[w][n].v[e] : (T)0;
+                    }
                 }
             }
         }
@@ -417,16 +427,27 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
 #pragma unroll
             for (int i = 0; i < NC; i++) part[i] += dpp_mov<0x128>(part[i]);       // lane ^ 8
         }
+        // The exchange across the four groups.  fp32 kernels are VALU-issue bound at 2-3 waves per SIMD: ds_bpermute runs on
+        // the LDS pipe and its latency hides behind the other waves (v_permlane*_swap instead: C4 PG(10) A half 5.04 ->
+        // 5.46 ms, B half 7.9 -> 9.3).  fp64 kernels run one wave per SIMD and wait out every round trip: there the
+        // swaps win (C3 CG fp64 A half 39.5 -> 37.3 ms).  Same bits either way.
+        if constexpr (sizeof(T) == 8) {
 #pragma unroll
-        for (int i = 0; i < NC; i++) part[i] += __shfl_xor(part[i], 16);
+            for (int i = 0; i < NC; i++) part[i] = xor_sum<16>(part[i]);
 #pragma unroll
-        for (int i = 0; i < NC; i++) part[i] += __shfl_xor(part[i], 32);
+            for (int i = 0; i < NC; i++) part[i] = xor_sum<32>(part[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NC; i++) part[i] += __shfl_xor(part[i], 16);
+#pragma unroll
+            for (int i = 0; i < NC; i++) part[i] += __shfl_xor(part[i], 32);
+        }
 #pragma unroll
         for (int i = 0; i < NC; i++) acc[i] += part[i];
     }
 
     // Same contract as RowEval::eval (store is not supported here: pq_cap == 0)
-    template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* = nullptr)
+    template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
     {
         n_eval++;
         double lpart = 0.0;
@@ -440,6 +461,8 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
 #pragma unroll
             for (int u = 0; u < G; u++) p[u] = u < n ? lane_dot(t[(G * b + u) < S ? (G * b + u) : 0]) : (T)0;
             const T pred = transpose_sum<n>(p);
+            if (store == pbuf) pv[b] = pred;
+            else if (store == qbuf) qv[b] = pred;
             const bool on = (unsigned)(64 * b + jlane) < nnz;
             const T xj = xr[b];
             if constexpr (WANT_F) lpart += on ? (double)xj * d_log((double)pred) : 0.0;
@@ -476,8 +499,30 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
         }
     }
 
-    __device__ __forceinline__ double logsum_cached(T) const { return 0.0; }
-    __device__ __forceinline__ void advance_cached(T) {}
+    // sum_j x_j log(p_j + alpha q_j) from the cached predictions (ref: the authors' TODO at src/poismf.c:191-193)
+    // `trusted` comes back false when some p_j + alpha q_j cancels to (almost) nothing: the point then sits on the boundary
+    // in every coordinate that prediction depends on (k = 1: always at alpha = max_step), where the snap-to-zero of the
+    // trial point -- which the cached form does not see -- decides between log(0) and log(rounding residue); the caller
+    // evaluates that trial directly instead.
+    __device__ __forceinline__ double logsum_cached(T alpha, bool& trusted) const
+    {
+        double lpart = 0.0;
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const bool on = (unsigned)(64 * b + jlane) < nnz;
+            const T pred = fma_t(alpha, qv[b], pv[b]);
+            bad = bad || (on && !(pred > pv[b] * (T)1e-4));
+            lpart += on ? (double)xr[b] * d_log((double)pred) : 0.0;
+        }
+        trusted = __builtin_amdgcn_ballot_w64(bad) == 0;
+        return wave_sum(lpart);
+    }
+    __device__ __forceinline__ void advance_cached(T alpha)
+    {
+#pragma unroll
+        for (int b = 0; b < NB; b++) pv[b] = fma_t(alpha, qv[b], pv[b]);
+    }
 
     // acc_c += sum_j F[ind_j, c]  (adjustment_Bsum's gather pass, ref: src/poismf.c:108-110)
     __device__ __forceinline__ void tile_colsum(T (&acc)[NC])

@@ -693,13 +693,19 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     // sum_j x_j log(p_j + alpha q_j) from the cached predictions: no access to the tile or to F at all.
     // This is the evaluation the reference's authors describe as the faster alternative for line searches
     // (ref: src/poismf.c:191-193, src/nonnegcg.c:291-294).
-    __device__ __forceinline__ double logsum_cached(T alpha) const
+    // `trusted` comes back false when some p_j + alpha q_j cancels to (almost) nothing (see RegEval::logsum_cached): the
+    // caller then evaluates that trial directly.
+    __device__ __forceinline__ double logsum_cached(T alpha, bool& trusted) const
     {
         double lpart = 0.0;
+        bool bad = false;
         for (unsigned j = lane; j < nnz; j += WAVE) {
-            const T pred = fma_t(alpha, qbuf[j], pbuf[j]);
+            const T pj = pbuf[j];
+            const T pred = fma_t(alpha, qbuf[j], pj);
+            bad = bad || !(pred > pj * (T)1e-4);
             lpart += (double)val[j] * d_log((double)pred);
         }
+        trusted = __builtin_amdgcn_ballot_w64(bad) == 0;
         return wave_sum(lpart);
     }
     // after an accepted step x <- x + alpha d the cached T.x moves along with it

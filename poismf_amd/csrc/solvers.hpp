@@ -255,7 +255,9 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
             }
             T r = ev.dot(bsum, trial);
             r += P.l2 * ev.dot(trial, trial);
-            f_new = r - (T)ev.logsum_cached(step) * P.w;
+            bool trusted;
+            f_new = r - (T)ev.logsum_cached(step, trusted) * P.w;
+            if (!trusted) f_new = fun_single(ev, P, bsum, trial);   // a prediction cancelled to ~0: evaluate at the snapped point
             if (!not_finite(f_new) && f_new <= f_cur - c_ls * step * dd) {
                 PMF_EW x[i] = trial[i];
                 accepted = true;

@@ -59,6 +59,39 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 __device__ __forceinline__ unsigned uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ bool uniform(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
 
+// ---- x[lane] + x[lane ^ 16] and x[lane] + x[lane ^ 32] without the LDS crossbar ------------------
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane rows (the upper half-wave) of one register
+// with the even rows (the lower half) of another: with both operands holding x, the two results are "the even rows' x
+// everywhere" and "the odd rows' x everywhere", whose sum is x + x[lane ^ 16] (^ 32) in every lane -- one VALU
+// instruction instead of a ds_bpermute round trip (~100 cycles) per exchange.  Same bits as x + __shfl_xor(x, 16):
+// the two addends are the same pair in either order.
+__device__ __forceinline__ unsigned swap_sum_bits16(unsigned v, unsigned& other)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    other = r[1];
+    return r[0];
+}
+__device__ __forceinline__ unsigned swap_sum_bits32(unsigned v, unsigned& other)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    other = r[1];
+    return r[0];
+}
+template <int W> __device__ __forceinline__ float xor_sum(float x)
+{
+    unsigned o;
+    const unsigned e = W == 16 ? swap_sum_bits16(__builtin_bit_cast(unsigned, x), o) : swap_sum_bits32(__builtin_bit_cast(unsigned, x), o);
+    return __builtin_bit_cast(float, e) + __builtin_bit_cast(float, o);
+}
+template <int W> __device__ __forceinline__ double xor_sum(double x)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    unsigned olo, ohi;
+    const unsigned elo = W == 16 ? swap_sum_bits16((unsigned)b, olo) : swap_sum_bits32((unsigned)b, olo);
+    const unsigned ehi = W == 16 ? swap_sum_bits16((unsigned)(b >> 32), ohi) : swap_sum_bits32((unsigned)(b >> 32), ohi);
+    return __builtin_bit_cast(double, ((unsigned long long)ehi << 32) | elo) + __builtin_bit_cast(double, ((unsigned long long)ohi << 32) | olo);
+}
+
 // ---- reductions ---------------------------------------------------------------------------------
 struct OpSum { template <class T> static __device__ __forceinline__ T f(T a, T b) { return a + b; } };
 struct OpMin {
