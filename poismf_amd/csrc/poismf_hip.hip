@@ -65,8 +65,11 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
     if constexpr (METHOD == K_PG) {
         pg_row(ev, a.P, x, shift);
     } else if constexpr (METHOD == K_CG) {
-        if (a.P.limit_step && ev.pq_cap > 0 && nnz <= (unsigned)ev.pq_cap) cg_row_cached(ev, a.P, shift, x, weighted);  // streamed rows only, see plan_geom
-        else cg_row(ev, a.P, shift, x, weighted);
+        // cached line search: streamed rows of the LDS engine (plan_geom decides), fp64 single-wave rows of the register engine
+        if constexpr (EV::MAY_CACHE) {
+            if (a.P.limit_step && ev.pq_cap > 0 && nnz <= (unsigned)ev.pq_cap) cg_row_cached(ev, a.P, shift, x, weighted);
+            else cg_row(ev, a.P, shift, x, weighted);
+        } else cg_row(ev, a.P, shift, x, weighted);
     } else {
         T prev[NC];
         PMF_EW prev[i] = x[i];

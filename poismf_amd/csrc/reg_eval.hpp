@@ -172,7 +172,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     int pq_cap;
     T* pbuf;
     T* qbuf;
-    T pv[NB], qv[NB];
+    static constexpr bool CACHED = sizeof(T) == 8 && NW_ == 1;   // compile-time: no trace of the cache in the other instances
+    static constexpr bool MAY_CACHE = CACHED;
+    T pv[CACHED ? NB : 1], qv[CACHED ? NB : 1];
 
     __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
@@ -195,7 +197,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
                 act[n * SN + e] = q * SN + e < k;
             }
         }
-        pq_cap = (sizeof(T) == 8 && NW == 1) ? 0x7fffffff : 0;
+        pq_cap = CACHED ? 0x7fffffff : 0;
         pbuf = (T*)(size_t)16; qbuf = (T*)(size_t)32;   // tags, never dereferenced
     }
 
@@ -311,28 +313,50 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             }
             if (lane == 0) red_l[wid] = lsum;
             __syncthreads();
-            // reads of up to eight waves' partials in flight at a time, sums in wave order
-            lsum = 0.0;
+            if constexpr (NW <= 8) {
+                SA part[NW][NS];
+                double lp[NW];
 #pragma unroll
-            for (int i = 0; i < NC; i++) tot[i] = (T)0;
-            constexpr int WB = NW < 8 ? NW : 8;
+                for (int w = 0; w < NW; w++) {        // all reads in flight, then the sums in wave order
+                    lp[w] = red_l[w];
 #pragma unroll
-            for (int w0 = 0; w0 < NW; w0 += WB) {
-                SA part[WB][NS];
-                double lp[WB];
-#pragma unroll
-                for (int w = 0; w < WB; w++) {
-                    lp[w] = red_l[w0 + w];
-#pragma unroll
-                    for (int n = 0; n < NS; n++) part[w][n] = red_slots[(w0 + w) * (G * NS) + g + G * n];
+                    for (int n = 0; n < NS; n++) part[w][n] = red_slots[w * (G * NS) + g + G * n];
                 }
+                lsum = 0.0;
 #pragma unroll
-                for (int w = 0; w < WB; w++) {
+                for (int i = 0; i < NC; i++) tot[i] = (T)0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
                     lsum += lp[w];
 #pragma unroll
                     for (int n = 0; n < NS; n++) {
 #pragma unroll
                         for (int e = 0; e < SN; e++) tot[n * SN + e] += act[n * SN + e] ? part[w][n].v[e] : (T)0;
+                    }
+                }
+            } else {
+                // (PMF_REGW16) eight waves' partials in flight at a time, sums in wave order
+                lsum = 0.0;
+#pragma unroll
+                for (int i = 0; i < NC; i++) tot[i] = (T)0;
+#pragma unroll
+                for (int w0 = 0; w0 < NW; w0 += 8) {
+                    SA part[8][NS];
+                    double lp[8];
+#pragma unroll
+                    for (int w = 0; w < 8; w++) {
+                        lp[w] = red_l[w0 + w];
+#pragma unroll
+                        for (int n = 0; n < NS; n++) part[w][n] = red_slots[(w0 + w) * (G * NS) + g + G * n];
+                    }
+#pragma unroll
+                    for (int w = 0; w < 8; w++) {
+                        lsum += lp[w];
+#pragma unroll
+                        for (int n = 0; n < NS; n++) {
+#pragma unroll
+                            for (int e = 0; e < SN; e++) tot[n * SN + e] += act[n * SN + e] ? part[w][n].v[e] : (T)0;
+                        }
                     }
                 }
             }
@@ -461,8 +485,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
 #pragma unroll
             for (int u = 0; u < G; u++) p[u] = u < n ? lane_dot(t[(G * b + u) < S ? (G * b + u) : 0]) : (T)0;
             const T pred = transpose_sum<n>(p);
-            if (store == pbuf) pv[b] = pred;
-            else if (store == qbuf) qv[b] = pred;
+            if constexpr (CACHED) {
+                if (store == pbuf) pv[b] = pred;
+                else if (store == qbuf) qv[b] = pred;
+            }
             const bool on = (unsigned)(64 * b + jlane) < nnz;
             const T xj = xr[b];
             if constexpr (WANT_F) lpart += on ? (double)xj * d_log((double)pred) : 0.0;
@@ -509,7 +535,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
         double lpart = 0.0;
         bool bad = false;
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
+        for (int b = 0; b < (CACHED ? NB : 0); b++) {
             const bool on = (unsigned)(64 * b + jlane) < nnz;
             const T pred = fma_t(alpha, qv[b], pv[b]);
             bad = bad || (on && !(pred > pv[b] * (T)1e-4));
@@ -521,7 +547,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     __device__ __forceinline__ void advance_cached(T alpha)
     {
 #pragma unroll
-        for (int b = 0; b < NB; b++) pv[b] = fma_t(alpha, qv[b], pv[b]);
+        for (int b = 0; b < (CACHED ? NB : 0); b++) pv[b] = fma_t(alpha, qv[b], pv[b]);
     }
 
     // acc_c += sum_j F[ind_j, c]  (adjustment_Bsum's gather pass, ref: src/poismf.c:108-110)

@@ -125,6 +125,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     static constexpr int SN = Slot<T>::N;
     static constexpr int NS = NC / SN;
     static constexpr bool PIPELINED = false;  // sweep_rows: no cross-row prefetch (the LDS tile has one set of index buffers)
+    static constexpr bool MAY_CACHE = true;   // cached CG line search where the launch geometry has room for it (pq_cap)
     static constexpr int PRE = PMF_PRE;       // 16-byte slots per lane a prefetched chunk may take (19: 1216 slots = 19 KiB)
     static_assert(NC % SN == 0, "a lane holds whole 16-byte slots");
 
