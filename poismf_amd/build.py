@@ -18,8 +18,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "poismf_hip.h")
-_ROW = ["poismf_hip.hip", "plan.hpp", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "wave_ops.hpp"]
-_HOST = ["poismf_hip_host.hip", "plan.hpp", "row_eval.hpp", "wave_ops.hpp"]
+_ROW = ["poismf_hip.hip", "plan.hpp", "devmem.hpp", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "wave_ops.hpp"]
+_HOST = ["poismf_hip_host.hip", "plan.hpp", "devmem.hpp", "row_eval.hpp", "wave_ops.hpp"]
 # unit -> (source files, first is the one compiled; extra flags).  poismf_hip.hip is compiled three times: one
 # translation unit per inner solver (its row kernels are the bulk of the compile time); the host side is its own file.
 UNITS = {
@@ -27,7 +27,7 @@ UNITS = {
     "poismf_hip_tncg": (_ROW, ["-DPMF_TU=1"]),
     "poismf_hip_cg": (_ROW, ["-DPMF_TU=2"]),
     "poismf_hip_pg": (_ROW, ["-DPMF_TU=3"]),
-    "coo_convert": (["coo_convert.hip"], []),
+    "coo_convert": (["coo_convert.hip", "devmem.hpp"], []),
     "serve": (["serve.hip"], []),
 }
 

@@ -126,12 +126,10 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
     TRY_OR_CLEAN(rocprim::reduce_by_key(tmp, tmp2, keys_b, vals_b, (unsigned int)n, keys_a, out_val, d_count,
                                         rocprim::plus<real_t>(), rocprim::equal_to<unsigned long long>(), stream));
     size_t uniq = 0;
-    TRY_OR_CLEAN(hipMemcpyAsync(&uniq, d_count, sizeof(size_t), hipMemcpyDeviceToHost, stream));
-    TRY_OR_CLEAN(hipStreamSynchronize(stream));
+    TRY_OR_CLEAN(pmf_download(&uniq, d_count, sizeof(size_t), stream));
     if (uniq > 0) {   // the trailing entry of the dropped triplets, if any
         unsigned long long last = 0;
-        TRY_OR_CLEAN(hipMemcpyAsync(&last, keys_a + (uniq - 1), sizeof(last), hipMemcpyDeviceToHost, stream));
-        TRY_OR_CLEAN(hipStreamSynchronize(stream));
+        TRY_OR_CLEAN(pmf_download(&last, keys_a + (uniq - 1), sizeof(last), stream));
         if (last == ~0ull) uniq--;
     }
     const unsigned g2 = (unsigned)std::min<size_t>((uniq + 255) / 256 + 1, 256 * 8);

@@ -403,6 +403,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     __device__ __forceinline__ T lane_dot(const SA (&w)[NS]) const
     {
         if constexpr (SN == 4) {
+#ifndef PMF_DOT_PLAIN
+            // pk_mul + pk_fma + add per step.  (-DPMF_DOT_PLAIN: mul + 3 fma -- fewer SIMD cycles on paper, a packed op takes two
+            // passes on CDNA4's SIMD-32, but one more instruction to issue: C4 PG(10) 12.91 -> 13.18 ms, same box.)
             typedef T V2 __attribute__((ext_vector_type(2)));
             V2 p = (V2){ w[0].v[0], w[0].v[1] } * (V2){ a[0], a[1] };
             p = __builtin_elementwise_fma((V2){ w[0].v[2], w[0].v[3] }, (V2){ a[2], a[3] }, p);
@@ -412,6 +415,18 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
                 p = __builtin_elementwise_fma((V2){ w[n].v[2], w[n].v[3] }, (V2){ a[4 * n + 2], a[4 * n + 3] }, p);
             }
             return p.x + p.y;
+#else
+            T p = w[0].v[0] * a[0];
+            p = fma_t(w[0].v[1], a[1], p);
+            p = fma_t(w[0].v[2], a[2], p);
+            p = fma_t(w[0].v[3], a[3], p);
+#pragma unroll
+            for (int n = 1; n < NS; n++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) p = fma_t(w[n].v[e], a[4 * n + e], p);
+            }
+            return p;
+#endif
         } else {
             T p = fma_t(w[0].v[1], a[1], w[0].v[0] * a[0]);
 #pragma unroll

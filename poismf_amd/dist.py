@@ -196,15 +196,22 @@ class ShardedAlternation:
     def _half(self, which, cnst_div):
         if self.method == "tncg" and self.stopped[which]:
             return
-        nseg = getattr(self.be, "segments", lambda w: 1)(which) if self.multi else 1
+        nseg = getattr(self.be, "segments", lambda w: 1)(which)
         ctx = getattr(self.be, "stream_context", None)
         comm = getattr(self.be, "comm_stream", None)
         n = 0
-        if nseg == 1 or comm is None:
+        if nseg == 1:
             n = self.be.half_sweep(which, self.step, cnst_div, self.early_stop)
             with (ctx() if ctx is not None else contextlib.nullcontext()):
                 if self.multi:
                     self._exchange(which, 0, 1)
+        elif comm is None or not self.multi:
+            # segments without a second stream (CPU backends of the tests, single rank): same order of work, no overlap
+            for j in range(nseg):
+                n = self.be.half_sweep(which, self.step, cnst_div, self.early_stop and j == nseg - 1, seg=j)
+                with (ctx() if ctx is not None else contextlib.nullcontext()):
+                    if self.multi:
+                        self._exchange(which, j, nseg)
         else:
             # segment j's rows travel on the communication stream while segment j + 1 computes
             for j in range(nseg):

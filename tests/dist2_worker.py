@@ -28,7 +28,7 @@ def main():
     be = pdist.HipBackend(csr, csc, dimA, dimB, k, use_float,
                           dict(method=method, l2_reg=l2, maxupd=60 if method == "tncg" else maxupd, limit_step=True, early_stop=early,
                                reuse_prev=True),
-                          rangesA[rank], rangesB[rank], 0)
+                          rangesA[rank], rangesB[rank], 0, segments=(2, 3))   # B half in 2, A half in 3 segments, exchanged one by one
     be.sess.set_factors(A0, B0)
     alt = pdist.ShardedAlternation(be, rangesA, rangesB, method, l2, 1e-7, early_stop=early, dims=(dimA, dimB))
     for _ in range(3):

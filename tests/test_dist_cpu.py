@@ -20,13 +20,18 @@ from tests import helpers as H
 class OracleShardBackend:
     """Per-rank compute for the CPU test: the oracle's half-sweep drivers on this rank's rows only."""
 
-    def __init__(self, csr, csc, A0, B0, method, l2, maxupd, shardA, shardB, is_float, early_stop=False):
+    def __init__(self, csr, csc, A0, B0, method, l2, maxupd, shardA, shardB, is_float, early_stop=False, nseg=(1, 1)):
         self.orc = bindings.Oracle(is_float)
         self.csr, self.csc = csr, csc
         self.A, self.B = torch.from_numpy(A0.copy()), torch.from_numpy(B0.copy())
         self.method, self.l2, self.maxupd = method, l2, maxupd
         self.shards = (shardB, shardA)
         self.early_stop = early_stop
+        self.nseg = nseg
+        self._unchanged = 0
+
+    def segments(self, which):
+        return self.nseg[which]
 
     def factor(self, which):
         return self.A if which else self.B
@@ -34,11 +39,19 @@ class OracleShardBackend:
     def shard(self, which):
         return self.shards[which]
 
-    def half_sweep(self, which, step, cnst_div, want_unchanged=False):
+    def half_sweep(self, which, step, cnst_div, want_unchanged=False, seg=None):
+        """seg = j: only segment j of the shard (cut as the C session cuts it); the unchanged-row count accumulates over
+        the segments of a half and is reported by the last one"""
         M = (self.A if which else self.B).numpy()
         F = (self.B if which else self.A).numpy()
         data, indices, indptr = self.csr if which else self.csc
         b, e = self.shards[which]
+        if seg is not None:
+            b, e = pdist.segment_of((b, e), seg, self.nseg[which])
+            if seg == 0:
+                self._unchanged = 0
+        else:
+            self._unchanged = 0
         ptr = (indptr[b:e + 1] - indptr[b]).astype(np.uint64)
         sl = slice(int(indptr[b]), int(indptr[e]))
         Ms = np.ascontiguousarray(M[b:e])
@@ -57,7 +70,8 @@ class OracleShardBackend:
             nz = np.diff(ptr.astype(np.int64)) > 0
             n = int(np.sum((((Mp - Ms) ** 2).sum(1) <= 1e-4) & nz))
         M[b:e] = Ms
-        return n
+        self._unchanged += n
+        return self._unchanged
 
 
 def _free_port():
@@ -68,7 +82,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, method, is_float, balanced, numiter, outdir):
+def _worker(rank, world, port, method, is_float, balanced, numiter, outdir, nseg=(1, 1)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     csr, csc, A0, B0 = H.small_problem(90, 70, 1500, 6, is_float, seed=11, powerlaw=True, empty_rows=(4,))
@@ -79,7 +93,7 @@ def _worker(rank, world, port, method, is_float, balanced, numiter, outdir):
         rA, rB = pdist.balanced_ranges(csr[2], world), pdist.balanced_ranges(csc[2], world)
     else:
         rA, rB = pdist.equal_ranges(90, world), pdist.equal_ranges(70, world)
-    be = OracleShardBackend(csr, csc, A0, B0, method, l2, maxupd, rA[rank], rB[rank], is_float)
+    be = OracleShardBackend(csr, csc, A0, B0, method, l2, maxupd, rA[rank], rB[rank], is_float, nseg=nseg)
     alt = pdist.ShardedAlternation(be, rA, rB, method, l2, 1e-7, early_stop=(method == "tncg"), dims=(90, 70))
     for _ in range(numiter):
         if not alt.sweep():
@@ -90,11 +104,13 @@ def _worker(rank, world, port, method, is_float, balanced, numiter, outdir):
 
 
 @pytest.mark.parametrize("method", ["pg", "cg", "tncg"])
-@pytest.mark.parametrize("balanced", [False, True])
-def test_world2_gloo_matches_unsharded_oracle(tmp_path, method, balanced):
+@pytest.mark.parametrize("balanced,nseg", [(False, (1, 1)), (True, (1, 1)), (True, (2, 3))])
+def test_world2_gloo_matches_unsharded_oracle(tmp_path, method, balanced, nseg):
+    """equal ranges, nnz-balanced (unequal) ranges, and halves cut into segments that are exchanged one by one (the
+    point-to-point exchange of poismf_amd/dist.py: every rank sends its rows to its peer and receives in place)"""
     is_float = False
     world, numiter = 2, 2
-    mp.spawn(_worker, args=(world, _free_port(), method, is_float, balanced, numiter, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), method, is_float, balanced, numiter, str(tmp_path), nseg), nprocs=world, join=True)
     csr, csc, A0, B0 = H.small_problem(90, 70, 1500, 6, is_float, seed=11, powerlaw=True, empty_rows=(4,))
     l2, maxupd, _ = harness.auto_defaults(method, 6)
     if method == "tncg":

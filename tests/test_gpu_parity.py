@@ -191,6 +191,37 @@ def test_session_matches_run_poismf(prec):
     assert np.array_equal(As, A) and np.array_equal(Bs, B)
 
 
+@pytest.mark.parametrize("method", ["pg", "cg", "tncg"])
+def test_segments_reproduce_the_unsegmented_half_sweep(prec, method):
+    """A half-sweep cut into segments (what the multi-GPU driver exchanges one by one while the next computes) is bit for
+    bit the unsegmented half-sweep: a row's arithmetic depends on its length class only, the column sums are computed by
+    segment 0, and the TNCG unchanged-row counter accumulates over the segments."""
+    dimA, dimB, k = 1500, 900, 50
+    csr, csc, A0, B0 = H.small_problem(dimA, dimB, 60000, k, prec, seed=8, powerlaw=True, empty_rows=(5,))
+    l2, maxupd, _ = harness.auto_defaults(method, k)
+    kw = dict(maxupd=40, early_stop=True) if method == "tncg" else dict(maxupd=maxupd)
+    res = []
+    for nseg in ((1, 1), (3, 4)):
+        s = api.Session(csr, csc, dimA, dimB, k, prec)
+        s.set_factors(A0, B0)
+        p = s.make_params(method, l2, **kw)
+        counts = []
+        for which in (0, 1):
+            if nseg[which] > 1:
+                assert s.set_segments(which, nseg[which]) == nseg[which]
+                dim = dimA if which else dimB
+                assert [s.segment_rows(which, j) for j in range(nseg[which])] == \
+                       [(dim * j // nseg[which], dim * (j + 1) // nseg[which]) for j in range(nseg[which])]
+                for j in range(nseg[which]):
+                    n = s.half_sweep(which, p, 1e-7, 1.0, want_unchanged=(method == "tncg" and j == nseg[which] - 1), seg=j)
+            else:
+                n = s.half_sweep(which, p, 1e-7, 1.0, want_unchanged=(method == "tncg"))
+            counts.append(n)
+        res.append(s.get_factors() + (counts,))
+        s.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+
+
 def test_sharded_sessions_reproduce_the_unsharded_result(prec):
     """two sessions, each owning half of the A rows and half of the B rows, exchanging their shards through
     the host after every half-sweep == one unsharded session (what the multi-GPU driver does with an
