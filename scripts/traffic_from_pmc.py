@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""traffic_from_pmc.py <dir> <sweeps>: fabric-side bytes per full sweep of the row-update kernels, from the
-summary.txt files scripts/profile_round.sh leaves in <dir>/pmc_f*/ (FETCH_SIZE) and <dir>/pmc_w*/ (WRITE_SIZE).
+"""traffic_from_pmc.py <dir>: fabric-side bytes per full sweep of the row-update kernels, from the summary.txt files
+scripts/profile_round.sh leaves in <dir>/pmc_f_*/ (FETCH_SIZE) and <dir>/pmc_w_*/ (WRITE_SIZE).
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB, and on gfx950 FETCH_SIZE tallies the 128-byte
 requests of 16-byte-per-lane loads at 64 bytes (MI355X_MICROARCH.md, section HBM).  Infinity-Cache hits are included,
 so this is an upper bound on DRAM traffic."""
@@ -10,7 +10,9 @@ import os
 import re
 import sys
 
-root, sweeps = sys.argv[1], float(sys.argv[2])
+root = sys.argv[1]
+# name -> (key in profiles/hbm_traffic.json, sweeps per profiled run = 2 x (warmup + steps) of scripts/profile_round.sh)
+RUNS = {"pg10": ("C4_pg_maxupd10_f32", 12), "pg1": ("C4_pg_maxupd1_f32", 12), "cg64": ("C4_cg_maxupd5_f64", 6)}
 
 
 def total(path, counter):
@@ -23,13 +25,12 @@ def total(path, counter):
     return tot
 
 
-out = {"_note": "fabric-side bytes per full sweep of the half_sweep_* launches on config C2, (2 * FETCH_SIZE + WRITE_SIZE) * 1024, "
-                "FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes (scripts/profile_round.sh); Infinity-Cache hits "
-                "are included, so this is an upper bound on DRAM traffic"}
-for tag, key in (("10", "pg_maxupd10_f32"), ("1", "pg_maxupd1_f32")):
-    f = os.path.join(root, f"pmc_f{tag}", "**", "summary.txt")
-    w = os.path.join(root, f"pmc_w{tag}", "**", "summary.txt")
-    ff, ww = glob.glob(f, recursive=True), glob.glob(w, recursive=True)
+out = {"_note": "fabric-side bytes per full sweep of the half_sweep_* launches on the 1M x 100K / 1e8-nnz matrix, "
+                "(2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes "
+                "(scripts/profile_round.sh); Infinity-Cache hits are included, so this is an upper bound on DRAM traffic"}
+for name, (key, sweeps) in RUNS.items():
+    ff = glob.glob(os.path.join(root, f"pmc_f_{name}", "**", "summary.txt"), recursive=True)
+    ww = glob.glob(os.path.join(root, f"pmc_w_{name}", "**", "summary.txt"), recursive=True)
     if ff and ww:
         out[key] = (2 * total(ff[0], "FETCH_SIZE") + total(ww[0], "WRITE_SIZE")) * 1024 / sweeps
 print(json.dumps(out, indent=1))
