@@ -5,8 +5,10 @@
  *
  *     libpoismf_hip_d.so   real_t = double
  *     libpoismf_hip_f.so   real_t = float      (compile this header with -DUSE_FLOAT)
+ *     libpoismf_hip_r.so   real_t = double, sparse_ix = int: the reference's R ABI (compile with -D_FOR_R,
+ *                          ref: src/poismf.h:75-89; same row kernels as libpoismf_hip_d.so)
  *
- * sparse_ix is size_t (the reference's C/Python ABI, ref: src/poismf.h:76).  No torch / HIP types
+ * sparse_ix is size_t otherwise (the reference's C/Python ABI, ref: src/poismf.h:76).  No torch / HIP types
  * appear in any signature: pointers and sizes only.  All "ref:" citations are relative to the
  * reference tree (david-cortes/poismf).
  *
@@ -22,6 +24,10 @@
 extern "C" {
 #endif
 
+/* ref: src/poismf.h:75-109.  -D_FOR_R selects the R ABI: int indices, double only (libpoismf_hip_r.so). */
+#ifdef _FOR_R
+  #undef USE_FLOAT
+#endif
 #ifndef real_t
   #ifdef USE_FLOAT
     #define real_t float
@@ -30,7 +36,11 @@ extern "C" {
   #endif
 #endif
 #ifndef sparse_ix
-  #define sparse_ix size_t
+  #ifdef _FOR_R
+    #define sparse_ix int
+  #else
+    #define sparse_ix size_t
+  #endif
 #endif
 #if defined(__GNUC__) || defined(__clang__)
   #define POISMF_HIP_API __attribute__((visibility("default")))

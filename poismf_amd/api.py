@@ -48,8 +48,9 @@ EXPORTED_SYMBOLS = (
 
 
 def load_library(use_float):
-    """dlopen libpoismf_hip_{d,f}.so (built in-tree by poismf_amd.build) and declare its prototypes."""
-    key = bool(use_float)
+    """dlopen libpoismf_hip_{d,f}.so (built in-tree by poismf_amd.build) and declare its prototypes.  use_float = "r" loads
+    libpoismf_hip_r.so, the reference's R ABI (int indices, double): same prototypes, index arrays are int32."""
+    key = "r" if use_float == "r" else bool(use_float)
     if key in _LIBS:
         return _LIBS[key]
     path = _build.lib_path(key)
@@ -57,7 +58,7 @@ def load_library(use_float):
         raise RuntimeError(f"{path} is missing: build it with `python -m poismf_amd.build` "
                            "(there is no CPU fallback for this path)")
     lib = C.CDLL(path)
-    r = C.c_float if key else C.c_double
+    r = C.c_float if key is True else C.c_double
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     lib.run_poismf.argtypes = [vp] * 8 + [sz] * 3 + [r] * 4 + [i, C.c_bool, sz, sz] + [C.c_bool] * 3 + [i]
     lib.run_poismf.restype = i

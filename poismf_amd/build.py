@@ -32,12 +32,26 @@ UNITS = {
 }
 
 
+# flavour -> flags: the reference builds its core twice for Python (ref: setup.py:225-243) and once for R with int indices
+# (ref: src/poismf.h:75-89); the R flavour differs on the host side only and links the double flavour's row kernels
+FLAVOURS = {"d": [], "f": ["-DUSE_FLOAT"], "r": ["-D_FOR_R"]}
+_KERNEL_UNITS = ("poismf_hip_tncg", "poismf_hip_cg", "poismf_hip_pg", "poismf_hip_all")
+
+
+def _flavour(use_float):
+    return use_float if isinstance(use_float, str) else ("f" if use_float else "d")
+
+
 def lib_path(use_float):
-    return os.path.join(HERE, "libpoismf_hip_f.so" if use_float else "libpoismf_hip_d.so")
+    """use_float: False / True (the two Python flavours) or a flavour name "d" / "f" / "r" """
+    return os.path.join(HERE, f"libpoismf_hip_{_flavour(use_float)}.so")
 
 
-def _obj_path(unit, use_float):
-    return os.path.join(CSRC, f"{unit}_{'f' if use_float else 'd'}.o")
+def _obj_path(unit, flavour):
+    flavour = _flavour(flavour)
+    if flavour == "r" and unit in _KERNEL_UNITS:
+        flavour = "d"
+    return os.path.join(CSRC, f"{unit}_{flavour}.o")
 
 
 def _digest(parts, files):
@@ -90,7 +104,7 @@ def up_to_date():
     travel with a snapshot of the tree (and file times do not survive one), so this is what decides whether a process
     on another machine -- or N ranks of one job at once -- may skip the compiler."""
     try:
-        return all(os.path.exists(lib_path(f)) for f in (False, True)) and open(STAMP).read().strip() == _source_hash()
+        return all(os.path.exists(lib_path(f)) for f in FLAVOURS) and open(STAMP).read().strip() == _source_hash()
     except OSError:
         return False
 
@@ -115,11 +129,13 @@ def _build_locked(force, verbose):
         flags.append("-Rpass-analysis=kernel-resource-usage")
     compiles = []
     digests = {}
-    for use_float in (False, True):
+    for flavour, fl_flags in FLAVOURS.items():
         for unit, (files, unit_flags) in _units().items():
             deps = [os.path.join(CSRC, f) for f in files] + [HEADER]
-            obj = _obj_path(unit, use_float)
-            cmd = [hipcc] + (["-DUSE_FLOAT"] if use_float else []) + flags + unit_flags + ["-c", os.path.join(CSRC, files[0]), "-o", obj]
+            obj = _obj_path(unit, flavour)
+            if obj in digests:
+                continue   # the R flavour's row kernels are the double flavour's objects
+            cmd = [hipcc] + fl_flags + flags + unit_flags + ["-c", os.path.join(CSRC, files[0]), "-o", obj]
             digests[obj] = _digest(cmd, deps)
             if force or not _fresh(obj, digests[obj]):
                 if verbose:
@@ -135,9 +151,9 @@ def _build_locked(force, verbose):
             _mark(obj, digests[obj])
     if failed:
         raise failed
-    for use_float in (False, True):
-        out = lib_path(use_float)
-        objs = [_obj_path(u, use_float) for u in _units()]
+    for flavour in FLAVOURS:
+        out = lib_path(flavour)
+        objs = [_obj_path(u, flavour) for u in _units()]
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
         digest = _digest(cmd + [digests[o] for o in objs], [])
         if force or not _fresh(out, digest):

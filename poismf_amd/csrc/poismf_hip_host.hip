@@ -304,28 +304,37 @@ int finish_half(Half& h, hipStream_t stream, int nseg = 1)
 int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* indptr, const sparse_ix* indices,
                size_t dimM, size_t dimF, size_t r0, size_t r1)
 {
-    static_assert(sizeof(sparse_ix) == sizeof(unsigned long long), "host indices are 64-bit");
     h.dimM = dimM; h.dimF = dimF; h.row_begin = r0; h.row_end = r1;
     const size_t nloc = r1 - r0;
-    const size_t base = indptr[r0];
-    h.nnz = indptr[r1] - base;
+    const size_t base = (size_t)indptr[r0];
+    h.nnz = (size_t)indptr[r1] - base;
     HIP_TRY(pmf_alloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1), stream));
     HIP_TRY(pmf_alloc(&h.d_indices, sizeof(unsigned) * (h.nnz ? h.nnz : 1), stream));
     HIP_TRY(pmf_alloc(&h.d_values, sizeof(real_t) * (h.nnz ? h.nnz : 1), stream));
-    HIP_TRY(pmf_upload(h.d_indptr, indptr + r0, sizeof(unsigned long long) * (nloc + 1), stream));
+    if constexpr (sizeof(sparse_ix) == sizeof(unsigned long long)) {
+        // C / Python ABI: size_t indices go up as they are and are narrowed to u32 by a kernel
+        HIP_TRY(pmf_upload(h.d_indptr, indptr + r0, sizeof(unsigned long long) * (nloc + 1), stream));
+        if (h.nnz) {
+            unsigned long long* d_wide = nullptr;
+            HIP_TRY(pmf_alloc(&d_wide, sizeof(unsigned long long) * h.nnz, stream));
+            hipError_t e = pmf_upload(d_wide, indices + base, sizeof(unsigned long long) * h.nnz, stream);
+            if (e == hipSuccess && poismf_hip_device_narrow(d_wide, h.nnz, h.d_indices, stream)) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            pmf_free(d_wide, stream);
+            HIP_TRY(e);
+        }
+    } else {
+        // R ABI: int indices are the device's width already; the row pointers are widened on the host (dim + 1 values)
+        std::vector<unsigned long long> wide(nloc + 1);
+        for (size_t i = 0; i <= nloc; i++) wide[i] = (unsigned long long)indptr[r0 + i];
+        HIP_TRY(pmf_upload(h.d_indptr, wide.data(), sizeof(unsigned long long) * (nloc + 1), stream));
+        HIP_TRY(pmf_upload(h.d_indices, indices + base, sizeof(unsigned) * h.nnz, stream));
+    }
     if (base != 0) {
         hipLaunchKernelGGL(rebase_indptr_kernel, dim3((unsigned)std::min<size_t>((nloc + 256) / 256, 2048)), dim3(256), 0, stream, h.d_indptr, nloc + 1,
                            (unsigned long long)base);
     }
-    if (h.nnz) {
-        unsigned long long* d_wide = nullptr;
-        HIP_TRY(pmf_alloc(&d_wide, sizeof(unsigned long long) * h.nnz, stream));
-        hipError_t e = pmf_upload(d_wide, indices + base, sizeof(unsigned long long) * h.nnz, stream);
-        if (e == hipSuccess && poismf_hip_device_narrow(d_wide, h.nnz, h.d_indices, stream)) e = hipErrorUnknown;
-        if (e == hipSuccess) e = pmf_upload(h.d_values, val + base, sizeof(real_t) * h.nnz, stream);   // (drains the narrowing kernel)
-        pmf_free(d_wide, stream);
-        HIP_TRY(e);
-    }
+    HIP_TRY(pmf_upload(h.d_values, val + base, sizeof(real_t) * h.nnz, stream));
     return finish_half(h, stream);
 }
 

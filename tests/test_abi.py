@@ -23,8 +23,9 @@ def _declared_symbols():
     return sorted(set(re.findall(r"^POISMF_HIP_API\s+[\w\s\*]*?\b(\w+)\s*\(", text, re.M)))
 
 
-@pytest.mark.parametrize("use_float", [False, True])
+@pytest.mark.parametrize("use_float", [False, True, "r"])
 def test_library_exports_header(use_float):
+    """the two Python flavours and the R-ABI flavour (int indices, ref src/poismf.h:75-89)"""
     lib = api.load_library(use_float)
     declared = _declared_symbols()
     assert sorted(api.EXPORTED_SYMBOLS) == declared

@@ -222,6 +222,26 @@ def test_segments_reproduce_the_unsegmented_half_sweep(prec, method):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
 
 
+@pytest.mark.parametrize("method", ["pg", "cg", "tncg"])
+def test_r_abi_flavour_is_bit_identical(method):
+    """libpoismf_hip_r.so (sparse_ix = int, double: what the reference's R build hands to run_poismf, ref src/poismf.h:75-89,
+    src/rwrapper.c:105-115) runs the same row kernels as libpoismf_hip_d.so: same bits from int32 index arrays"""
+    import ctypes as C
+    csr, csc, A0, B0 = H.small_problem(700, 500, 30000, 20, False, seed=12, powerlaw=True, empty_rows=(9,))
+    l2, maxupd, _ = harness.auto_defaults(method, 20)
+    A, B, args = gpu_run(csr, csc, A0, B0, method, 2, 20, maxupd=min(maxupd, 60))
+    lib = api.load_library("r")
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    csr_i = (csr[0], i32(csr[1]), i32(csr[2]))
+    csc_i = (csc[0], i32(csc[1]), i32(csc[2]))
+    Ar, Br = A0.copy(), B0.copy()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.run_poismf(ptr(Ar), ptr(csr_i[0]), ptr(csr_i[2]), ptr(csr_i[1]), ptr(Br), ptr(csc_i[0]), ptr(csc_i[2]), ptr(csc_i[1]),
+                        700, 500, 20, args["l2_reg"], 0.0, 1.0, 1e-7, {"tncg": 1, "cg": 2, "pg": 3}[method], True, 2, args["maxupd"],
+                        True, False, True, 1)
+    assert rc == 0 and np.array_equal(Ar, A) and np.array_equal(Br, B)
+
+
 def test_sharded_sessions_reproduce_the_unsharded_result(prec):
     """two sessions, each owning half of the A rows and half of the B rows, exchanging their shards through
     the host after every half-sweep == one unsharded session (what the multi-GPU driver does with an
