@@ -239,6 +239,15 @@ POISMF_HIP_API int poismf_hip_session_eval_stats(poismf_hip_session *s, int whic
  * of special arguments (+-0, -1, +-inf, NaN) on which they disagree.  Returns 0 on success. */
 POISMF_HIP_API int poismf_hip_selftest_log(size_t n, unsigned long long *worst_ulp, unsigned *mismatched_specials);
 
+/* Serving from the session's resident factors: the same results as predict_multiple
+ * (ref: src/pred.c:42-64) and as topN with a_vec = row `user` of A (ref: src/topN.c:112-284), without the per-call copy
+ * of the factors that the host-pointer drop-ins of section 1d make.  Index arrays are host arrays.  Return 0, 1 (device
+ * error / out of memory) or 2 (an index out of range, or topN's invalid combinations, ref src/topN.c:126-130). */
+POISMF_HIP_API int poismf_hip_session_predict(poismf_hip_session *s, const sparse_ix *ixA, const sparse_ix *ixB, size_t n, real_t *out);
+POISMF_HIP_API int poismf_hip_session_topn(poismf_hip_session *s, size_t user,
+                          const sparse_ix *include_ix, size_t n_include, const sparse_ix *exclude_ix, size_t n_exclude,
+                          sparse_ix *outp_ix, real_t *outp_score, size_t n_top);
+
 /* Which row-kernel instances the most recent half-sweep of half `which` launched, as text ("kernel<instance> rows=N;"
  * per launch), NUL-terminated and truncated to cap bytes; returns the untruncated length.  Reporting only. */
 POISMF_HIP_API size_t poismf_hip_session_plan(poismf_hip_session *s, int which, char *buf, size_t cap);

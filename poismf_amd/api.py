@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_nnz", "poismf_hip_selftest_log", "poismf_hip_session_eval_stats",
     "poismf_hip_session_create_coo", "poismf_hip_session_stream", "poismf_hip_session_factors_dirty", "poismf_hip_session_run",
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
+    "poismf_hip_session_predict", "poismf_hip_session_topn",
 )
 
 
@@ -95,6 +96,10 @@ def load_library(use_float):
     lib.poismf_hip_session_segment_rows.restype = i
     lib.poismf_hip_half_sweep_segment.argtypes = [vp, i, C.POINTER(lib.params_t), r, r, i, C.POINTER(sz)]
     lib.poismf_hip_half_sweep_segment.restype = i
+    lib.poismf_hip_session_predict.argtypes = [vp, vp, vp, sz, vp]
+    lib.poismf_hip_session_predict.restype = i
+    lib.poismf_hip_session_topn.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, sz]
+    lib.poismf_hip_session_topn.restype = i
     lib.poismf_hip_session_plan.argtypes = [vp, i, C.c_char_p, sz]
     lib.poismf_hip_session_plan.restype = sz
     lib.poismf_hip_session_run.argtypes = [vp, C.POINTER(lib.params_t), sz, i]
@@ -471,6 +476,32 @@ class Session:
 
     def nnz(self, which):
         return self.lib.poismf_hip_session_nnz(self.h, int(which))
+
+    def predict(self, ix_u, ix_i):
+        """A[ix_u[i]] . B[ix_i[i]] from the resident factors (ref: src/pred.c:42-64)"""
+        ix_u = np.ascontiguousarray(ix_u, dtype=np.uint64)
+        ix_i = np.ascontiguousarray(ix_i, dtype=np.uint64)
+        out = np.empty(len(ix_u), np.float32 if self.use_float else np.float64)
+        rc = self.lib.poismf_hip_session_predict(self.h, _ptr(ix_u), _ptr(ix_i), len(ix_u), _ptr(out))
+        if rc == 2:
+            raise IndexError("user / item index out of range")
+        if rc:
+            raise MemoryError("poismf_hip_session_predict failed")
+        return out
+
+    def topn(self, user, top_n=10, include_ix=(), exclude_ix=(), output_score=False):
+        """top-N items of user `user` (row of the resident A) by score, descending (ref: src/topN.c:112-284)"""
+        inc = np.ascontiguousarray(include_ix, dtype=np.uint64)
+        exc = np.ascontiguousarray(exclude_ix, dtype=np.uint64)
+        ix = np.empty(top_n, np.uint64)
+        sc = np.empty(top_n if output_score else 0, np.float32 if self.use_float else np.float64)
+        rc = self.lib.poismf_hip_session_topn(self.h, int(user), _ptr(inc) if len(inc) else None, len(inc), _ptr(exc) if len(exc) else None,
+                                              len(exc), _ptr(ix), _ptr(sc) if output_score else None, int(top_n))
+        if rc == 2:
+            raise ValueError("invalid combination of include / exclude / top_n, or an index out of range")
+        if rc:
+            raise MemoryError("poismf_hip_session_topn failed")
+        return ix, sc
 
     def plan(self, which):
         """the launches of the most recent half-sweep of half `which`: [(kernel instance, rows), ...]"""

@@ -158,6 +158,12 @@ __global__ __launch_bounds__(WAVE* COLSUM_FINAL_WAVES) void colsum_final_kernel(
 // =================================================================================================
 // Host side
 // =================================================================================================
+// serve.hip (cores on device-resident factors)
+int poismf_hip_serve_predict(const real_t* dA, const real_t* dB, const sparse_ix* ixA, const sparse_ix* ixB, size_t n, int k, real_t* out,
+                             size_t* max_a, size_t* max_b);
+int poismf_hip_serve_topn(const real_t* d_a, const real_t* dB, int k, const sparse_ix* include_ix, size_t n_include,
+                          const sparse_ix* exclude_ix, size_t n_exclude, sparse_ix* outp_ix, real_t* outp_score, size_t n_top, size_t n);
+int poismf_hip_serve_topn_check(const sparse_ix*& include_ix, size_t n_include, const sparse_ix*& exclude_ix, size_t n_exclude, size_t n_top, size_t n);
 // coo_convert.hip (rocPRIM-based helpers)
 int poismf_hip_device_sort_rows(const unsigned long long* d_indptr, size_t nloc, unsigned base, unsigned* d_perm, unsigned* d_len_sorted,
                                 hipStream_t stream);
@@ -986,6 +992,33 @@ size_t poismf_hip_session_plan(poismf_hip_session* s, int which, char* buf, size
         buf[n] = 0;
     }
     return t.size();
+}
+
+// Serving from the session's resident factors: predict_multiple (ref: src/pred.c:42-64) and topN for the
+// user in row `user` of A (ref: src/topN.c:112-284) without copying the factors per call.
+int poismf_hip_session_predict(poismf_hip_session* s, const sparse_ix* ixA, const sparse_ix* ixB, size_t n, real_t* out)
+{
+    if (n == 0) return 0;
+    for (size_t i = 0; i < n; i++)
+        if ((size_t)ixA[i] >= s->dimA || (size_t)ixB[i] >= s->dimB) return 2;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return poismf_hip_serve_predict(s->dA, s->dB, ixA, ixB, n, (int)s->k, out, nullptr, nullptr);
+}
+
+int poismf_hip_session_topn(poismf_hip_session* s, size_t user, const sparse_ix* include_ix, size_t n_include, const sparse_ix* exclude_ix,
+                            size_t n_exclude, sparse_ix* outp_ix, real_t* outp_score, size_t n_top)
+{
+    if (user >= s->dimA) return 2;
+    if (const int rc = poismf_hip_serve_topn_check(include_ix, n_include, exclude_ix, n_exclude, n_top, s->dimB)) return rc;
+    for (size_t i = 0; include_ix && i < n_include; i++)
+        if ((size_t)include_ix[i] >= s->dimB) return 2;
+    for (size_t i = 0; exclude_ix && i < n_exclude; i++)
+        if ((size_t)exclude_ix[i] >= s->dimB) return 2;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return poismf_hip_serve_topn(s->dA + user * s->k, s->dB, (int)s->k, include_ix, n_include, exclude_ix, n_exclude, outp_ix, outp_score,
+                                 n_top, s->dimB);
 }
 
 int poismf_hip_session_set_segments(poismf_hip_session* s, int which, int nseg)

@@ -512,3 +512,31 @@ def test_topn_gpu(prec, case):
     assert np.array_equal(ix2, ix) and len(sc2) == 0
     with pytest.raises(ValueError):
         api._call_topN(a, B, none, np.arange(49999, dtype=np.uint64), 5, 0, 1)   # n_exclude > n - n_top
+
+
+def test_session_resident_predict_and_topn(prec):
+    """the session variants serve from the factors already in HBM: same answers as the host-pointer drop-ins
+    (predict_multiple, ref src/pred.c:42-64; topN, ref src/topN.c:112-284), bit for bit, and the same argument checks"""
+    dimA, dimB, k = 400, 3000, 50
+    csr, csc, A0, B0 = H.small_problem(dimA, dimB, 20000, k, prec, seed=21)
+    s = api.Session(csr, csc, dimA, dimB, k, prec)
+    s.set_factors(A0, B0)
+    s.half_sweep(0, s.make_params("pg", 1e3, maxupd=1), 1e-9, 1.0)
+    A, B = s.get_factors()
+    rng = np.random.default_rng(5)
+    iu = rng.integers(0, dimA, 5000).astype(np.uint64)
+    ii = rng.integers(0, dimB, 5000).astype(np.uint64)
+    out = np.empty(len(iu), A.dtype)
+    api._predict_multiple(out, A, B, iu, ii, 1)
+    assert np.array_equal(s.predict(iu, ii), out)
+    none = np.empty(0, np.uint64)
+    for inc, exc, nt in ((none, none, 10), (np.sort(rng.choice(dimB, 200, replace=False)).astype(np.uint64), none, 12),
+                         (none, np.sort(rng.choice(dimB, 500, replace=False)).astype(np.uint64), 9)):
+        ix0, sc0 = api._call_topN(A[37], B, inc, exc, nt, 1, 1)
+        ix1, sc1 = s.topn(37, nt, inc, exc, output_score=True)
+        assert np.array_equal(ix0, ix1) and np.array_equal(sc0, sc1)
+    with pytest.raises(IndexError):
+        s.predict(np.array([dimA], np.uint64), np.array([0], np.uint64))
+    with pytest.raises(ValueError):
+        s.topn(0, 5, np.array([1, 2], np.uint64), np.array([3], np.uint64))      # include and exclude together
+    s.close()
