@@ -847,7 +847,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             // (TNC keeps the tile size its length class names: in fp32 its results move in the last bits with the size of
             // the instance -- 62 of 900 rows in tests/test_gpu_parity.py's segment test -- and a row must not depend on
             // which other rows share its shard; PG and CG are bit-identical across instances and may ride along)
-            const bool ride = p->method != POISMF_TNCG;
+            const bool ride = p->method != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
             const int S = reg_steps_for(ride ? b.max_nnz : b.cls);
             if (!launches.empty() && launches.back().nw == 1 && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || (ride && b.count < 4096u)) && launches.back().begin + launches.back().count == b.begin)
@@ -859,7 +859,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (regw_ok && b.cls <= regw_nnz_max(p->method)) {
             // medium rows: 2, 4 or 8 waves share a row, each keeps its part of the tile in registers
             const int nw = regw_waves_for(b.cls, p->method);
-            const bool ride = p->method != POISMF_TNCG;
+            const bool ride = p->method != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
             const int S = regw_steps_for(ride ? b.max_nnz : b.cls, nw);
             if (!launches.empty() && launches.back().nw == nw && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || (ride && b.count < 2048u)) && launches.back().begin + launches.back().count == b.begin)
