@@ -469,7 +469,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
         // The exchange across the four groups.  fp32 kernels are VALU-issue bound at 2-3 waves per SIMD: ds_bpermute runs on
         // the LDS pipe and its latency hides behind the other waves (v_permlane*_swap instead: C4 PG(10) A half 5.04 ->
         // 5.46 ms, B half 7.9 -> 9.3).  fp64 kernels run one wave per SIMD and wait out every round trip: there the
-        // swaps win (C3 CG fp64 A half 39.5 -> 37.3 ms).  Same bits either way.
+        // swaps win (C3 CG fp64 A half 39.5 -> 37.3 ms).  Same bits either way.  (Swaps in the multi-wave fp32 kernels only:
+        // C4 PG(10) B half 7.92 -> 8.60 ms.  Grouping all selects of a butterfly level before its DPP adds, to save the
+        // s_nop wait states: A half 5.10 -> 5.81 ms -- the extra live registers cost more than the 59 s_nops per pass.)
         if constexpr (sizeof(T) == 8) {
 #pragma unroll
             for (int i = 0; i < NC; i++) part[i] = xor_sum<16>(part[i]);
