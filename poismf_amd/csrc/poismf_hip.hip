@@ -33,7 +33,11 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
     T* out_p = a.Mp != nullptr ? a.Mp + (size_t)(a.row_offset + lrow) * (size_t)a.ldM : nullptr;
     T x[NC];
     if (nnz == 0) {  // rows without data are forced to zero every half (quirk Q7)
-        PMF_EW x[i] = (T)0;
+        // (built here, behind an opaque asm: as loop invariants of the row loop these zeros -- and wm1 below -- cost the
+        // S = 28 instances their last registers and went to scratch)
+        T z = (T)0;
+        asm volatile("" : "+v"(z));
+        PMF_EW x[i] = z;
         ev.store_vec(out, x);
         if (out_p != nullptr) ev.store_vec(out_p, x);
         return;
@@ -50,7 +54,9 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
         T cs[NC];
         PMF_EW cs[i] = (T)0;
         ev.tile_colsum(cs);
-        const T wm1 = a.P.w - (T)1.;
+        T w_here = a.P.w;
+        asm volatile("" : "+v"(w_here));
+        const T wm1 = w_here - (T)1.;
         PMF_EW {
             shift[i] = cs[i] * wm1;
             shift[i] = shift[i] + bs[i];
@@ -85,7 +91,9 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
     if (out_p != nullptr) ev.store_vec(out_p, x);
     // per-row evaluation counts for the pass-weighted effective traffic (a plain read-modify-write: the row
     // has one owner; a shared counter here costs 4x the kernel time in contention)
+#ifndef PMF_PROBE
     if (a.eval_rows != nullptr && ev.lane == 0 && ev.wid == 0) a.eval_rows[lrow] += ev.n_eval;
+#endif
 }
 
 // A wavefront (or, NW > 1, a workgroup of NW wavefronts) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the
@@ -131,12 +139,20 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
         unsigned t0 = ticket(), t1 = ticket();
         RowDesc d0 = fetch(t0), d1 = fetch(t1);
         if (t0 < a.nrows) ev.fetch_meta(a.indices + (((unsigned long long)d0.p0_hi << 32) | d0.p0_lo), d0.nnz);
+#ifdef PMF_PROBE
+        unsigned probe_i = 0;
+#endif
         while (t0 < a.nrows) {
             const unsigned long long p0 = ((unsigned long long)d0.p0_hi << 32) | d0.p0_lo;
             if (d0.nnz != 0) ev.gather(a.values + p0, d0.nnz);                  // indices are here: request the tile
             const unsigned t2 = ticket();
             const RowDesc d2 = fetch(t2);
             if (t1 < a.nrows) ev.fetch_meta(a.indices + (((unsigned long long)d1.p0_hi << 32) | d1.p0_lo), d1.nnz);
+#ifdef PMF_PROBE
+            ev.probe = (a.eval_rows != nullptr && blockIdx.x == 5 && threadIdx.x < WAVE && probe_i < 60) ? a.eval_rows + 16 * probe_i : nullptr;
+            if (ev.probe != nullptr && ev.lane == 0) { ev.probe[10] = (unsigned)__builtin_amdgcn_s_memtime(); ev.probe[11] = d0.nnz; }
+            probe_i++;
+#endif
             solve_row<EV, T, NC, METHOD>(a, ev, bs, d0.lrow, d0.nnz);
             t0 = t1; d0 = d1;
             t1 = t2; d1 = d2;
@@ -241,7 +257,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(reg_waves(
 // one wave 0.06; 200-nonzero rows 0.137 on eight waves).
 constexpr int regw_waves(int tile_regs, int method, int nw)
 {
-    const int w = reg_waves(tile_regs, method);
+    // (PG: the cross-wave scratch pointers and wave index are 8 more registers than the one-wave kernel keeps; without the
+    // allowance the S = 28 instances sat at 3 waves per SIMD with 20-28 bytes of scratch)
+    const int w = reg_waves(tile_regs + (method == K_PG ? 8 : 0), method);
     return nw >= 16 && w < 4 ? 4 : (nw >= 8 && w < 2 ? 2 : w);   // eight waves are two per SIMD, sixteen four
 }
 template <class T, int METHOD, int S, int G, int NS, int NW>

@@ -1021,6 +1021,16 @@ int poismf_hip_session_topn(poismf_hip_session* s, size_t user, const sparse_ix*
                                  n_top, s->dimB);
 }
 
+#ifdef PMF_PROBE
+// development only (not in the header): the raw per-row counters of half `which`, which a -DPMF_PROBE build fills with stamps
+extern "C" __attribute__((visibility("default"))) int poismf_hip_debug_eval_rows(poismf_hip_session* s, int which, unsigned* out, size_t n)
+{
+    Half& h = s->half[which ? 1 : 0];
+    if (h.d_eval_rows == nullptr) return 1;
+    return pmf_download(out, h.d_eval_rows, sizeof(unsigned) * std::min(n, h.row_end - h.row_begin), s->stream) != hipSuccess;
+}
+#endif
+
 int poismf_hip_session_set_segments(poismf_hip_session* s, int which, int nseg)
 {
     HIP_TRY(hipSetDevice(s->device));

@@ -157,11 +157,17 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     int lane, g, jg, wid;
     int jlane;      // JG g + jg
     bool cls8, cls4, cls2, cls1;
-    int elem[NC];
+    struct ElemOf {   // factor dimension held in element i of this lane (computed, not kept: registers are what sets the waves per SIMD)
+        int g;
+        __device__ __forceinline__ int operator[](int i) const { return (g + G * (i / SN)) * SN + i % SN; }
+    } elem;
     bool act[NC];
     bool slot_on[NS];
     unsigned nnz;   // nonzeros of the row held by THIS wave
     unsigned n_eval; // passes over the tile since the caller last reset it (wave-uniform; reporting only)
+#ifdef PMF_PROBE
+    unsigned* probe = nullptr;
+#endif
     unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
     int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
     unsigned* ticket_word;
@@ -184,7 +190,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
         ticket_word = (unsigned*)(smem + 2 * RED_BYTES);
         F = F_;
         k = geo.k; ldF = geo.ldF; s_load = geo.s_load; zero_row = geo.zero_row;
-        g = lane & (G - 1); jg = lane / G; wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
+        g = lane & (G - 1); elem.g = g; jg = lane / G; wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
         jlane = JG * g + jg;
         cls8 = (lane & 8) != 0; cls4 = (lane & 4) != 0; cls2 = (lane & 2) != 0; cls1 = (lane & 1) != 0;
 #pragma unroll
@@ -193,7 +199,6 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             slot_on[n] = q < s_load;
 #pragma unroll
             for (int e = 0; e < SN; e++) {
-                elem[n * SN + e] = q * SN + e;
                 act[n * SN + e] = q * SN + e < k;
             }
         }
@@ -313,6 +318,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             }
             if (lane == 0) red_l[wid] = lsum;
             __syncthreads();
+            PMF_STAMP(*this, 7);
             if constexpr (NW <= 8) {
                 SA part[NW][NS];
                 double lp[NW];
@@ -471,7 +477,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
         // 5.46 ms, B half 7.9 -> 9.3).  fp64 kernels run one wave per SIMD and wait out every round trip: there the
         // swaps win (C3 CG fp64 A half 39.5 -> 37.3 ms).  Same bits either way.  (Swaps in the multi-wave fp32 kernels only:
         // C4 PG(10) B half 7.92 -> 8.60 ms.  Grouping all selects of a butterfly level before its DPP adds, to save the
-        // s_nop wait states: A half 5.10 -> 5.81 ms -- the extra live registers cost more than the 59 s_nops per pass.)
+        // s_nop wait states: A half 5.10 -> 5.81 ms -- the extra live registers cost more than the 59 s_nops per pass.
+        // The matrix pipe as the adder: the four groups are the contraction index of a 16x16x4 MFMA's B operand, so
+        // mfma(ones, part[i]) leaves the sum in every lane -- four MFMAs instead of eight bpermutes and eight adds, and 8-13
+        // fewer registers; but 32 issue cycles each: A half 5.09 -> 5.52 ms, B half 7.92 -> 8.52.)
         if constexpr (sizeof(T) == 8) {
 #pragma unroll
             for (int i = 0; i < NC; i++) part[i] = xor_sum<16>(part[i]);
@@ -491,6 +500,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
     {
         n_eval++;
+        PMF_STAMP(*this, 0);
         double lpart = 0.0;
         T part[NC];
 #pragma unroll
@@ -501,7 +511,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             T p[G];
 #pragma unroll
             for (int u = 0; u < G; u++) p[u] = u < n ? lane_dot(t[(G * b + u) < S ? (G * b + u) : 0]) : (T)0;
+            if constexpr (b == 0) PMF_STAMP(*this, 1);
             const T pred = transpose_sum<n>(p);
+            if constexpr (b == 0) PMF_STAMP(*this, 2);
             if constexpr (CACHED) {
                 if (store == pbuf) pv[b] = pred;
                 else if (store == qbuf) qv[b] = pred;
@@ -511,6 +523,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             if constexpr (WANT_F) lpart += on ? (double)xj * d_log((double)pred) : 0.0;
             if constexpr (WANT_G) {
                 const T coef = on ? coef_div(sgn * xj, pred) : (T)0;
+                if constexpr (b == 0) PMF_STAMP(*this, 3);
                 static_for<0, n>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
                     const T c = group_bcast<G, u>(coef);
@@ -520,16 +533,20 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
                         for (int e = 0; e < SN; e++) part[m * SN + e] = fma_t(c, t[G * b + u][m].v[e], part[m * SN + e]);
                     }
                 });
+                if constexpr (b == 0) PMF_STAMP(*this, 4);
             }
         });
+        PMF_STAMP(*this, 5);
         if constexpr (NW > 1) {
             T tot[NC];
 #pragma unroll
             for (int i = 0; i < NC; i++) tot[i] = (T)0;
             if constexpr (WANT_G) combine_groups(part, tot);
+            PMF_STAMP(*this, 6);
             double lsum = 0.0;
             if constexpr (WANT_F) lsum = wave_sum(lpart);
             combine_waves(tot, lsum);
+            PMF_STAMP(*this, 8);
             if constexpr (WANT_G) {
 #pragma unroll
                 for (int i = 0; i < NC; i++) acc[i] += tot[i];
@@ -537,6 +554,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             return lsum;
         } else {
             if constexpr (WANT_G) combine_groups(part, acc);
+            PMF_STAMP(*this, 6);
             if constexpr (WANT_F) return wave_sum(lpart);
             else return 0.0;
         }

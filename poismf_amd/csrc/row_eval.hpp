@@ -25,6 +25,19 @@
 #pragma once
 #include "wave_ops.hpp"
 
+// -DPMF_PROBE (development): shader-clock stamps of the phases of ONE evaluation (the 4th of a row) in one workgroup, written
+// over the per-row evaluation counters; scripts/probes/probe_phases.py reads them back.
+#ifdef PMF_PROBE
+#define PMF_STAMP(ev, i)                                                                                     \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        if ((ev).probe != nullptr && (ev).n_eval == 4 && (ev).lane == 0) (ev).probe[i] = (unsigned)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+#else
+#define PMF_STAMP(ev, i) do {} while (0)
+#endif
+
 namespace pmf {
 
 // Optional phase timers (build with -DPMF_TIMING): per-wave shader-clock totals of the phases of row_eval,
@@ -165,6 +178,9 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     const T* val;
     unsigned nnz;
     unsigned n_eval;  // passes over the row's tile since the caller last reset it (wave-uniform; reporting only)
+#ifdef PMF_PROBE
+    unsigned* probe = nullptr;
+#endif
 #ifdef PMF_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif

@@ -37,6 +37,7 @@ __device__ __forceinline__ void pg_row(EV& ev, const RowParams<T>& P, T (&x)[NC]
             x[i] = x[i] * P.cnst_div;                              // a *= 1 / (1 + 2 l2 step)
             x[i] = (x[i] > (T)0) ? x[i] : (T)0;                    // a = max(a, 0)
         }
+        PMF_STAMP(ev, 9);
     }
 }
 
