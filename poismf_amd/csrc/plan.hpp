@@ -42,6 +42,8 @@ template <class T> struct HalfArgs {
     unsigned* n_unchanged;
     unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
     unsigned* eval_rows;              // != nullptr (profiling sessions): [local row] += passes over that row's tile
+    unsigned long long* team_buf;     // team launches (several CUs per row, reg_eval.hpp M_ > 1): arrival counters, mailboxes, exchange slots
+    unsigned* team_err;               // set by a team launch that gave up (an exchange timed out); sticky until the session reads it
 };
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
@@ -127,6 +129,22 @@ int regw_steps_for(unsigned max_nnz, int nw)
     return reg_steps_for(std::max(32u, share));
 }
 
+// teams (row_eval.hpp: TEAM_*): members and tile steps for rows of up to max_nnz nonzeros (members 0: not a team row).
+// Two CUs where they hold the row; the 28-step instance (no scratch) where three are needed anyway.
+// Below TEAM_MIN_NNZ a row's tile (k = 50 fp64: 400 B per nonzero) is resident in one CU's LDS: the LDS engine keeps it.
+constexpr unsigned TEAM_MIN_NNZ = 385;
+struct TeamShape { int members, steps; };
+inline TeamShape team_shape_for(unsigned max_nnz)
+{
+    const unsigned per_step = (unsigned)(REG_JG * TEAM_NW);
+    if (max_nnz < TEAM_MIN_NNZ) return { 0, 0 };
+    if (max_nnz <= 2u * 32u * per_step) return { 2, 32 };
+    if (max_nnz <= 3u * 28u * per_step) return { 3, 28 };
+    if (max_nnz <= 3u * 32u * per_step) return { 3, 32 };
+    if (max_nnz <= 4u * 32u * per_step) return { 4, 32 };
+    return { 0, 0 };
+}
+
 // Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
 constexpr unsigned LONG_ROW_NNZ = 8192;
 constexpr int LONG_NW = 8;
@@ -144,6 +162,7 @@ int slots_per_lane(size_t k)
 // One row-bin launch: everything the planner decided, minus the solver (which selects the translation unit).
 struct OneLaunch {
     int reg_S, nw, s_load, spl;   // register-engine steps (0: LDS engine), waves per row, slots per factor row, slots per lane
+    int team;                     // > 1: CUs per row (team launch)
     bool generic_only;
     hipStream_t main_stream, bin_stream, long_stream;
     size_t lds;

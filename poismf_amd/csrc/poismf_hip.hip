@@ -84,7 +84,7 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
         if (a.early_stop) {                                             // ref: src/poismf.c:393-396
             PMF_EW prev[i] = prev[i] - x[i];
             const T moved = ev.dot(prev, prev);
-            if ((double)moved <= 1e-4 && ev.lane == 0 && ev.wid == 0) atomicAdd(a.n_unchanged, 1u);
+            if ((double)moved <= 1e-4 && ev.lane == 0 && ev.wid == 0 && ev.member == 0) atomicAdd(a.n_unchanged, 1u);
         }
     }
     ev.store_vec(out, x);
@@ -92,7 +92,7 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
     // per-row evaluation counts for the pass-weighted effective traffic (a plain read-modify-write: the row
     // has one owner; a shared counter here costs 4x the kernel time in contention)
 #ifndef PMF_PROBE
-    if (a.eval_rows != nullptr && ev.lane == 0 && ev.wid == 0) a.eval_rows[lrow] += ev.n_eval;
+    if (a.eval_rows != nullptr && ev.lane == 0 && ev.wid == 0 && ev.member == 0) a.eval_rows[lrow] += ev.n_eval;
 #endif
 }
 
@@ -271,6 +271,137 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(regw_w
     sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
 }
 
+// Teams of M workgroups per row (reg_eval.hpp, M_ > 1).  A workgroup joins the next open team of ITS XCD in arrival order
+// (same XCD: the granules then travel through one L2), so whatever the dispatcher does, a team's members are on the chip.
+// The team's first member draws the rows from the launch's queue and posts each ticket in the team's mailbox one row ahead;
+// it starts a row only once the team is complete, and if the queue runs dry before that, it posts the end-of-rows ticket and
+// leaves (late members find it and leave too).
+template <class T, int METHOD, int S, int G, int NS, int NW, int M>
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) void half_sweep_team_kernel(const HalfArgs<T> a)
+{
+    using EV = RegEval<T, S, G, NS, NW, M>;
+    constexpr int NC = EV::NC;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
+    EV ev;
+    ev.init(a.geom, a.F, smem);
+    T bs[NC];
+    ev.load_vec(a.bsum, bs);
+    const RowDesc* desc = a.desc + a.perm_begin;
+    unsigned* arrive = (unsigned*)a.team_buf;                 // [8] per XCD
+    unsigned* err = a.team_err;
+    unsigned* box = ev.ticket_slot();
+    if (threadIdx.x == 0) {
+        // a grid too small to leave M workgroups on every XCD forms its teams chip-wide (it is a multiple of M: no team
+        // stays incomplete); a full-size grid may leave up to M - 1 workgroups per XCD without a team, idle until the rows run out
+        unsigned xcc = 0;
+        if (gridDim.x >= 8u * 4u * (unsigned)M) {
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+        }
+        const unsigned n = atomicAdd(arrive + xcc, 1u);
+        box[0] = xcc * TEAM_SLOTS_PER_XCD + n / (unsigned)M;
+        box[1] = n % (unsigned)M;
+        if (n / (unsigned)M >= TEAM_SLOTS_PER_XCD) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned team = uniform(box[0]) % TEAM_SLOTS;
+    ev.member = (int)uniform(box[1]);
+    __syncthreads();
+    ev.team_words = a.team_buf + TEAM_HEAD_WORDS + (size_t)team * TEAM_WORDS;
+    ev.team_err = err;
+    unsigned long long* mail = ev.team_words;                 // [2]: { ticket, row number } of the row with that parity
+    unsigned long long* here = ev.team_words + 2;             // [M_MAX]: member m has arrived
+    constexpr unsigned END = 0xffffffffu;
+    if (ev.member != 0 && threadIdx.x == 0) gran_store(here + ev.member, 1ull);
+
+    // leader: wait for the team, or for the rows to run out
+    if (ev.member == 0) {
+        if (threadIdx.x == 0) {
+            unsigned full = 0;
+            for (unsigned spins = 0; !full; spins++) {
+                full = 1;
+                for (int m = 1; m < M; m++) full &= gran_load(here + m) != 0ull;
+                if (full) break;
+                if (__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.nrows || spins > TEAM_SPIN_LIMIT ||
+                    __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            box[0] = full;
+        }
+        __syncthreads();
+        const bool full = uniform(box[0]) != 0;
+        __syncthreads();
+        if (!full) {
+            if (threadIdx.x == 0) gran_store(mail + 1, ((unsigned long long)1u << 32) | END);   // the first row has number 1
+            return;
+        }
+    }
+
+    // rows: number 1, 2, ..; the ticket of row number i travels in mailbox slot i % 2
+    unsigned rowno = 1, t = 0;
+    if (ev.member == 0) {
+        if (threadIdx.x == 0) {
+            box[0] = atomicAdd(a.queue, 1u);
+            gran_store(mail + 1, ((unsigned long long)1u << 32) | (box[0] < a.nrows ? box[0] : END));
+        }
+        __syncthreads();
+        t = uniform(box[0]);
+        __syncthreads();
+    }
+    for (;;) {
+        unsigned t_next = 0;
+        if (ev.member == 0) {
+            // the next row's ticket goes out now: the others find it waiting when they finish this row
+            if (t < a.nrows) {
+                if (threadIdx.x == 0) {
+                    box[0] = atomicAdd(a.queue, 1u);
+                    gran_store(mail + ((rowno + 1) & 1u), ((unsigned long long)(rowno + 1) << 32) | (box[0] < a.nrows ? box[0] : END));
+                }
+                __syncthreads();
+                t_next = uniform(box[0]);
+                __syncthreads();
+            }
+        } else {
+            if (threadIdx.x == 0) {
+                unsigned long long v = 0;
+                for (unsigned spins = 0;; spins++) {
+                    v = gran_load(mail + (rowno & 1u));
+                    if ((unsigned)(v >> 32) == rowno) break;
+                    if (spins > TEAM_SPIN_LIMIT || ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = END;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                box[0] = (unsigned)v;
+            }
+            __syncthreads();
+            t = uniform(box[0]);
+            __syncthreads();
+        }
+        if (t >= a.nrows) break;
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        const RowDesc d = desc[t];
+        const unsigned nnz = uniform(d.nnz);
+        const unsigned long long p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
+#ifdef PMF_PROBE
+        const unsigned long long t_row0 = __builtin_amdgcn_s_memtime();
+        ev.probe_wait = 0;
+#endif
+        ev.begin_row(a.indices + p0, a.values + p0, nnz);
+        solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d.lrow), nnz);
+#ifdef PMF_PROBE
+        // (a probe build leaves the per-row counters to the stamps) low half: cycles / 256 spent waiting for the team, high half: of the whole row
+        if (a.eval_rows != nullptr && threadIdx.x == 0 && ev.member == 0)
+            a.eval_rows[uniform(d.lrow)] = (unsigned)std::min<unsigned long long>(0xffffu, ev.probe_wait >> 8) |
+                                           ((unsigned)std::min<unsigned long long>(0xffffu, (__builtin_amdgcn_s_memtime() - t_row0) >> 8) << 16);
+#endif
+        rowno++;
+        t = t_next;
+    }
+}
+
 namespace {
 
 constexpr int MAX_DEVICES = 64;        // per-device caches of kernel attributes below
@@ -357,6 +488,20 @@ template <int METHOD, int S, int NS, int NW> int launch_regw(hipStream_t stream,
     return 0;
 }
 
+// team launches: CG on doubles with two slots per lane (k = 50 fp64) is what asks for them
+template <int M, int S> int launch_team(hipStream_t stream, int method, const HalfArgs<real_t>& a)
+{
+    if constexpr (tu_has(K_CG) && sizeof(real_t) == 8 && REG_G == 16) {
+        if (method != POISMF_CG) return 1;
+        auto kern = half_sweep_team_kernel<real_t, K_CG, S, REG_G, 2, TEAM_NW, M>;
+        // as many workgroups as CUs: each takes a CU's whole register file (one wave of 512 per SIMD)
+        const unsigned grid = (unsigned)std::min<size_t>((size_t)a.nrows * M, (size_t)t_num_cu / M * M);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * TEAM_NW), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    } else return 1;
+}
+
 template <int S, int NS, int NW> int launch_regw_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (S * REG_JG < 32) return 1;
@@ -411,6 +556,13 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
 {
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
+    if (o.team > 1) {
+        if (o.team == 2 && o.reg_S == 32) return launch_team<2, 32>(o.main_stream, method, a);
+        if (o.team == 3 && o.reg_S == 28) return launch_team<3, 28>(o.main_stream, method, a);
+        if (o.team == 3 && o.reg_S == 32) return launch_team<3, 32>(o.main_stream, method, a);
+        if (o.team == 4 && o.reg_S == 32) return launch_team<4, 32>(o.main_stream, method, a);
+        return 1;
+    }
     if (o.reg_S > 0) {
         if (o.nw > 1) {
             if constexpr (REG_G == 16) rc = launch_regw_steps<1>(o.main_stream, o.nw, o.reg_S, method, a, o.grid_mult);

@@ -222,6 +222,9 @@ struct poismf_hip_session {
     real_t* d_partial = nullptr;
     unsigned* d_counter = nullptr;
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
+    unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
+    unsigned* d_team_err = nullptr;         // sticky error word of the team launches
+    bool team_launched = false;             // since the error word was last read
     int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -512,7 +515,9 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     if (pmf_alloc(&s->d_bsum, k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * MAX_LAUNCHES, s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 8), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads)
+    if (pmf_alloc(&s->d_team_err, sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->d_team_err, 0, sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (cached_stream(device, &s->aux_stream)) return fail();
     if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) return fail();
     if (hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail();
@@ -625,6 +630,8 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     pmf_free(s->d_partial, s->stream);
     pmf_free(s->d_counter, s->stream);
     pmf_free(s->d_queue, s->stream);
+    pmf_free(s->d_team, s->stream);
+    pmf_free(s->d_team_err, s->stream);
     (void)hipStreamSynchronize(s->stream);   // the stream-ordered frees have run
     if (aux) release_stream(s->device, aux);
     if (own) release_stream(s->device, own);
@@ -675,12 +682,28 @@ int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, 
     return 0;
 }
 
+// Team launches (reg_eval.hpp, M_ > 1) give up instead of hanging when an exchange between CUs times out; the word they set
+// is read where the session synchronises anyway.  Nonzero: the factors are not to be trusted.
+static int team_check(poismf_hip_session* s)
+{
+    if (!s->team_launched) return 0;
+    unsigned err = 0;
+    HIP_TRY(pmf_download(&err, s->d_team_err, sizeof(unsigned), s->stream));
+    s->team_launched = false;
+    if (err != 0) {
+        fprintf(stderr, "poismf_hip: a multi-CU row launch gave up (code %u)\n", err);
+        (void)hipMemsetAsync(s->d_team_err, 0, sizeof(unsigned), s->stream);
+        return 1;
+    }
+    return 0;
+}
+
 int poismf_hip_session_get_factors(poismf_hip_session* s, real_t* A_host, real_t* B_host)
 {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(pmf_download(A_host, s->dA, s->dimA * s->k * sizeof(real_t), s->stream));
     HIP_TRY(pmf_download(B_host, s->dB, s->dimB * s->k * sizeof(real_t), s->stream));
-    return 0;
+    return team_check(s);
 }
 
 void poismf_hip_session_profile(poismf_hip_session* s, int enable)
@@ -819,7 +842,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
     // solver) are merged into one launch.
-    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; };
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; };
     std::vector<Launch> launches;
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots (32 for doubles, two slots per lane), and 24-bit row ids / 32-bit
@@ -832,6 +855,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // (kernel-resource-usage: CG with 40 steps of two slots spills 360 bytes per lane even at one wave per SIMD, 36 steps 60)
     const unsigned reg_max = reg_ns == 2 && REG_G == 16 ? (p->method == POISMF_TNCG ? 112u : p->method == POISMF_CG ? 144u : reg_nnz_max(p->method))
                                                         : reg_nnz_max(p->method);
+    // teams: CG on doubles with two slots per lane (k = 50 fp64: 25 slots), rows handed out through the queue
+    static const bool no_team = getenv("POISMF_HIP_NO_TEAM") != nullptr;  // testing knob
+    static const bool static_rows_ = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;
+    const bool team_ok = !no_team && !static_rows_ && reg_ok && reg_ns == 2 && REG_G == 16 && sizeof(real_t) == 8 && p->method == POISMF_CG;
     static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
     if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
@@ -853,7 +880,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 (launches.back().reg_S == S || (ride && b.count < 4096u)) && launches.back().begin + launches.back().count == b.begin)
                 launches.back().count += b.count;
             else
-                launches.push_back({ b.begin, b.count, g, 1, S });
+                launches.push_back({ b.begin, b.count, g, 1, S, 0 });
             continue;
         }
         if (regw_ok && b.cls <= regw_nnz_max(p->method)) {
@@ -865,8 +892,20 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 (launches.back().reg_S == S || (ride && b.count < 2048u)) && launches.back().begin + launches.back().count == b.begin)
                 launches.back().count += b.count;
             else
-                launches.push_back({ b.begin, b.count, g, nw, S });
+                launches.push_back({ b.begin, b.count, g, nw, S, 0 });
             continue;
+        }
+        if (team_ok) {
+            // rows whose tile fits the registers of two to four CUs, not of one: a team per row (reg_eval.hpp, M_ > 1)
+            const TeamShape ts = team_shape_for(b.max_nnz);
+            if (ts.members > 0) {
+                if (!launches.empty() && launches.back().team == ts.members && launches.back().reg_S == ts.steps &&
+                    launches.back().begin + launches.back().count == b.begin)
+                    launches.back().count += b.count;
+                else
+                    launches.push_back({ b.begin, b.count, g, TEAM_NW, ts.steps, ts.members });
+                continue;
+            }
         }
         if (!no_long && b.cls > long_thr) {
             // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
@@ -883,7 +922,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             if (!launches.empty() && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
                 launches.back().count += b.count;
             else
-                launches.push_back({ b.begin, b.count, g, LONG_NW, 0 });
+                launches.push_back({ b.begin, b.count, g, LONG_NW, 0, 0 });
             continue;
         }
         if (!launches.empty() && launches.back().reg_S == 0 && launches.back().geom.cap == g.cap &&
@@ -891,7 +930,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             launches.back().begin + launches.back().count == b.begin)
             launches.back().count += b.count;
         else
-            launches.push_back({ b.begin, b.count, g, 1, 0 });
+            launches.push_back({ b.begin, b.count, g, 1, 0, 0 });
     }
     static const bool static_rows = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;  // testing knob
     const bool dynamic = !is_pg && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
@@ -919,7 +958,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             char txt[192];
             const char* m = is_pg ? "pg" : p->method == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
-            if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
+            if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
+            else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
             else if (L.reg_S > 0) snprintf(txt, sizeof txt, "half_sweep_regw_kernel<%s,%s,S=%d,NW=%d> rows=%u;", t, m, L.reg_S, L.nw, L.count);
             else snprintf(txt, sizeof txt, "half_sweep_kernel<%s,%s,NW=%d,%s cap=%d> rows=%u;", t, m, L.nw, L.geom.resident ? "resident" : "streamed", L.geom.cap, L.count);
             s->last_plan[which] += txt;
@@ -940,6 +980,17 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         // the queue (CG fp32 on C2: 3.87 ms with tickets, 3.35 ms without).
         const bool one_wave_reg = L.reg_S > 0 && L.nw == 1;
         if (one_wave_reg) a.queue = nullptr;
+        a.team_buf = nullptr; a.team_err = s->d_team_err;
+        if (L.team > 1) {
+            if (a.queue == nullptr) {            // teams always draw their rows from a queue
+                a.queue = s->d_queue + MAX_LAUNCHES + (launch_no % 8);
+                HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(unsigned), s->stream));
+            }
+            if (s->d_team == nullptr && pmf_alloc(&s->d_team, (size_t)TEAM_BUF_BYTES, s->stream) != hipSuccess) return 1;
+            HIP_TRY(hipMemsetAsync(s->d_team, 0, (size_t)TEAM_BUF_BYTES, s->stream));
+            a.team_buf = s->d_team;
+            s->team_launched = true;
+        }
         unsigned grid_mult = one_wave_reg ? 32 : 2;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
@@ -949,7 +1000,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
             OneLaunch o;
-            o.reg_S = L.reg_S; o.nw = L.nw; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
+            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
             static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
             o.generic_only = generic_only;
             o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
@@ -1131,7 +1182,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
         if (hipStreamSynchronize(s->stream) != hipSuccess) return 1;
         if (stopped_earlyA && stopped_earlyB) break;
     }
-    return 0;
+    return team_check(s);
 }
 }  // namespace
 

@@ -131,7 +131,27 @@ __device__ __forceinline__ void fold8_banked(const float (&q)[8], float (&r)[4])
 // ceil(nnz / NW_) rounded up to a whole step; every wave keeps its own copy of the solver state and runs the same
 // wave-uniform control flow; the NW_ partial gradients / log-likelihood sums of an evaluation are added through LDS in
 // wave order behind a workgroup barrier, so all copies stay bit-identical (the scheme of RowEval's long-row path).
-template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval {
+// tagged 8-byte granules between CUs (MI355X_MICROARCH "inter-workgroup visibility": 8-byte agent-scope atomics on both sides
+// are coherent across XCDs without fences; a granule is written by ONE store, so data and tag arrive together)
+__device__ __forceinline__ void gran_store(unsigned long long* p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long gran_load(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// M_ > 1: a TEAM of M_ workgroups (one per CU) shares one row, for rows whose tile fits no single CU's registers (k = 50 fp64,
+// 1000 nonzeros: 400 KB).  Member m keeps nonzeros [m NW_ C, (m + 1) NW_ C) spread over its NW_ waves as above; every wave of
+// every member keeps its own copy of the solver state and runs the same control flow.  An evaluation first adds up the
+// member's waves through LDS, then wave 0 publishes the member's sums as tagged granules, collects the other members' and
+// adds them in member order (every member ends with the same bits), and hands the totals to its workgroup through LDS.
+// Tags count the team's exchanges; two slots per member alternate (a member can be at most one exchange ahead of the
+// slowest: it needs everybody's granules of exchange n before it can publish n + 1, and everybody publishes n only after
+// reading n - 1).  Teams form in arrival order per XCD (poismf_hip.hip, half_sweep_team_kernel), so a team's members are
+// resident by construction and a launch makes progress with any two workgroups of an XCD on the chip.
+template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> struct RegEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
@@ -142,8 +162,12 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     static constexpr int NW = NW_;
     static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
     static constexpr int KP = G * NS * SN;        // elements of a (padded) k-vector in the cross-wave scratch
-    static constexpr int RED_BYTES = NW_ * KP * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16);   // one set of cross-wave scratch
-    static constexpr int SMEM_BYTES = NW_ > 1 ? 2 * RED_BYTES + 16 : 0;
+    static constexpr int M = M_;
+    // one set of cross-wave scratch: NW partial k-vectors and NW scalars (teams: NW x TEAM_SC scalars)
+    static constexpr int RED_BYTES = NW_ * KP * (int)sizeof(T) + (M_ > 1 ? NW_ * 8 * TEAM_SC : 16 * ((NW_ * 8 + 15) / 16));
+    static constexpr int TEAM_BYTES = M_ > 1 ? KP * (int)sizeof(T) + 8 * TEAM_SC : 0;           // team totals: a k-vector and the scalars
+    static constexpr int SMEM_BYTES = (NW_ > 1 ? 2 * RED_BYTES + 16 : 0) + TEAM_BYTES;
+    static_assert(M_ == 1 || (sizeof(T) == 8 && NW_ > 1 && NS_ * Slot<T>::N <= WAVE / G_), "teams: doubles, one element per group to publish");
     static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
 
     SA t[S][NS];    // the tile
@@ -167,10 +191,17 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     unsigned n_eval; // passes over the tile since the caller last reset it (wave-uniform; reporting only)
 #ifdef PMF_PROBE
     unsigned* probe = nullptr;
+    unsigned long long probe_wait = 0;   // teams: cycles wave 0 spent polling the other members' granules
 #endif
     unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
     int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
     unsigned* ticket_word;
+    // team state (M > 1)
+    unsigned long long* team_words;   // this team's words of HalfArgs::team_buf
+    unsigned* team_err;               // != 0: some exchange of this launch timed out, give up
+    T* team_tot;                      // LDS: the team's totals
+    int member;                       // 0 .. M - 1 (0 when M == 1)
+    unsigned xseq;                    // exchanges so far
     // Cached line search (solvers.hpp, cg_row_cached): the predictions p_j = F_j . x and q_j = F_j . d of the nonzero each
     // lane finishes stay in registers (pv / qv, one per batch); pbuf / qbuf are only tags that tell eval() which of the
     // two a pass is to keep.  Used by the fp64 single-wave kernels (pq_cap > 0): one wave per SIMD, where an Armijo trial
@@ -178,7 +209,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     int pq_cap;
     T* pbuf;
     T* qbuf;
-    static constexpr bool CACHED = sizeof(T) == 8 && NW_ == 1;   // compile-time: no trace of the cache in the other instances
+    static constexpr bool CACHED = sizeof(T) == 8 && (NW_ == 1 || M_ > 1);   // compile-time: no trace of the cache in the other instances
     static constexpr bool MAY_CACHE = CACHED;
     T pv[CACHED ? NB : 1], qv[CACHED ? NB : 1];
 
@@ -188,6 +219,8 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
         red_base = smem;
         red_sel = 0;
         ticket_word = (unsigned*)(smem + 2 * RED_BYTES);
+        team_tot = (T*)(smem + 2 * RED_BYTES + 16);
+        member = 0; xseq = 0; team_words = nullptr; team_err = nullptr;
         F = F_;
         k = geo.k; ldF = geo.ldF; s_load = geo.s_load; zero_row = geo.zero_row;
         g = lane & (G - 1); elem.g = g; jg = lane / G; wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
@@ -243,7 +276,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     }
     __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
     {
-        if (jg == 0 && wid == 0) {
+        if (jg == 0 && wid == 0 && member == 0) {
 #pragma unroll
             for (int n = 0; n < NS; n++) {
                 if (act[n * SN + SN - 1]) {          // whole slot inside the row
@@ -270,8 +303,8 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     __device__ __forceinline__ void my_share(unsigned nnz_row, unsigned& c0, unsigned& mine) const
     {
         if constexpr (NW > 1) {
-            const unsigned C = ((nnz_row + NW - 1) / NW + JG - 1) / JG * JG;
-            c0 = (unsigned)wid * C;
+            const unsigned C = ((nnz_row + NW * M - 1) / (NW * M) + JG - 1) / JG * JG;
+            c0 = (unsigned)(member * NW + wid) * C;
             mine = c0 < nnz_row ? (nnz_row - c0 < C ? nnz_row - c0 : C) : 0u;
         } else {
             c0 = 0u; mine = nnz_row;
@@ -295,8 +328,112 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     }
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
 
+    // M > 1, every wave of the member, after the member's own waves have been added up (tot / sc identical in all of them):
+    // the k-vector (vec) and TEAM_SC scalars cross the team
+    __device__ __forceinline__ void team_exchange(T (&tot)[NC], double (&sc)[TEAM_SC], bool vec)
+    {
+        if constexpr (M > 1) {
+            xseq++;
+            double* team_l = (double*)(team_tot + KP);
+            if (wid == 0) {
+                const unsigned long long tag = (unsigned long long)xseq << 32;
+                unsigned long long* slots = team_words + 2 + TEAM_M_MAX + (size_t)(xseq & 1u) * TEAM_M_MAX * TEAM_GRAN;
+                // lane (jg, g) carries element jg of its NC (the four groups hold the same values); lanes 0 .. TEAM_SC - 1 a scalar each
+                const bool carrier = vec && jg < NC;
+                const bool scalar = lane < TEAM_SC;
+                T mine = tot[0];
+#pragma unroll
+                for (int i = 1; i < NC; i++) mine = jg == i ? tot[i] : mine;
+                double mysc = sc[0];
+#pragma unroll
+                for (int j = 1; j < TEAM_SC; j++) mysc = lane == j ? sc[j] : mysc;
+                if (carrier) {
+                    const unsigned long long b = __builtin_bit_cast(unsigned long long, (double)mine);
+                    gran_store(slots + member * TEAM_GRAN + 2 * lane, (b & 0xffffffffull) | tag);
+                    gran_store(slots + member * TEAM_GRAN + 2 * lane + 1, (b >> 32) | tag);
+                }
+                if (scalar) {
+                    const unsigned long long b = __builtin_bit_cast(unsigned long long, mysc);
+                    gran_store(slots + member * TEAM_GRAN + 128 + 2 * lane, (b & 0xffffffffull) | tag);
+                    gran_store(slots + member * TEAM_GRAN + 129 + 2 * lane, (b >> 32) | tag);
+                }
+                T sum = (T)0;
+                double lt = 0.0;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    T pv = mine;
+                    double pl = mysc;
+                    if (m != member) {
+#ifdef PMF_PROBE
+                        const unsigned long long t_wait0 = __builtin_amdgcn_s_memtime();
+#endif
+                        const unsigned long long* theirs = slots + m * TEAM_GRAN;
+                        unsigned long long a0 = tag, a1 = tag, l0 = tag, l1 = tag;
+                        unsigned spins = 0;
+                        for (;;) {
+                            if (carrier) { a0 = gran_load(theirs + 2 * lane); a1 = gran_load(theirs + 2 * lane + 1); }
+                            if (scalar) { l0 = gran_load(theirs + 128 + 2 * lane); l1 = gran_load(theirs + 129 + 2 * lane); }
+                            const bool ok = (a0 >> 32) == xseq && (a1 >> 32) == xseq && (l0 >> 32) == xseq && (l1 >> 32) == xseq;
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((++spins & 255u) == 0 && (spins > TEAM_SPIN_LIMIT || __hip_atomic_load(team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                                if (lane == 0) __hip_atomic_store(team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                        pv = (T)__builtin_bit_cast(double, (a0 & 0xffffffffull) | (a1 << 32));
+                        pl = __builtin_bit_cast(double, (l0 & 0xffffffffull) | (l1 << 32));
+#ifdef PMF_PROBE
+                        probe_wait += __builtin_amdgcn_s_memtime() - t_wait0;
+#endif
+                    }
+                    sum = m == 0 ? pv : sum + pv;
+                    lt = m == 0 ? pl : lt + pl;
+                }
+                if (carrier) team_tot[elem[jg < NC ? jg : 0]] = sum;
+                if (scalar) team_l[lane] = lt;
+            }
+            __syncthreads();
+            if (vec) {
+#pragma unroll
+                for (int n = 0; n < NS; n++) {
+                    const SA v = *(const SA*)(team_tot + (g + G * n) * SN);
+#pragma unroll
+                    for (int e = 0; e < SN; e++) tot[n * SN + e] = act[n * SN + e] ? v.v[e] : (T)0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TEAM_SC; j++) sc[j] = team_l[j];
+        }
+    }
+    // M > 1: TEAM_SC scalars (wave-uniform in every wave) summed over the member's waves, then over the team
+    __device__ __forceinline__ void combine_scalars(double (&sc)[TEAM_SC])
+    {
+        if constexpr (M > 1) {
+            double* red_l = (double*)(red_base + red_sel * RED_BYTES + NW * KP * sizeof(T));
+            red_sel ^= 1;
+            double mysc = sc[0];
+#pragma unroll
+            for (int j = 1; j < TEAM_SC; j++) mysc = lane == j ? sc[j] : mysc;
+            if (lane < TEAM_SC) red_l[wid * TEAM_SC + lane] = mysc;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TEAM_SC; j++) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) t += red_l[w * TEAM_SC + j];   // same address in every lane: a broadcast read
+                sc[j] = t;
+            }
+            T none[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) none[i] = (T)0;
+            team_exchange(none, sc, false);
+        }
+    }
+
     // NW > 1: add up the NW waves' partial results (fixed order; every wave ends with the same bits)
-    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum)
+    // vec == false (wave-uniform): only the scalar travels
+    __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum, bool vec = true)
     {
         if constexpr (NW > 1) {
             // Alternating scratch sets: a wave may run ahead into the NEXT combine (other set) while a slow wave still
@@ -307,7 +444,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             red_sel ^= 1;
             // whole 16-byte slots through LDS (the partial sums of elements past k are zero: tile and point are)
             SA* red_slots = (SA*)red_part;
-            if (jg == 0) {
+            if (jg == 0 && (M == 1 || vec)) {
 #pragma unroll
                 for (int n = 0; n < NS; n++) {
                     SA v;
@@ -320,25 +457,37 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             __syncthreads();
             PMF_STAMP(*this, 7);
             if constexpr (NW <= 8) {
-                SA part[NW][NS];
                 double lp[NW];
 #pragma unroll
-                for (int w = 0; w < NW; w++) {        // all reads in flight, then the sums in wave order
-                    lp[w] = red_l[w];
-#pragma unroll
-                    for (int n = 0; n < NS; n++) part[w][n] = red_slots[w * (G * NS) + g + G * n];
-                }
+                for (int w = 0; w < NW; w++) lp[w] = red_l[w];
                 lsum = 0.0;
 #pragma unroll
-                for (int i = 0; i < NC; i++) tot[i] = (T)0;
+                for (int w = 0; w < NW; w++) lsum += lp[w];
+                if (M == 1 || vec) {
+                    SA part[NW][NS];
 #pragma unroll
-                for (int w = 0; w < NW; w++) {
-                    lsum += lp[w];
+                    for (int w = 0; w < NW; w++) {        // all reads in flight, then the sums in wave order
 #pragma unroll
-                    for (int n = 0; n < NS; n++) {
-#pragma unroll
-                        for (int e = 0; e < SN; e++) tot[n * SN + e] += act[n * SN + e] ? part[w][n].v[e] : (T)0;
+                        for (int n = 0; n < NS; n++) part[w][n] = red_slots[w * (G * NS) + g + G * n];
                     }
+#pragma unroll
+                    for (int i = 0; i < NC; i++) tot[i] = (T)0;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+#pragma unroll
+                        for (int n = 0; n < NS; n++) {
+#pragma unroll
+                            for (int e = 0; e < SN; e++) tot[n * SN + e] += act[n * SN + e] ? part[w][n].v[e] : (T)0;
+                        }
+                    }
+                }
+                if constexpr (M > 1) {
+                    double sc[TEAM_SC];
+#pragma unroll
+                    for (int j = 0; j < TEAM_SC; j++) sc[j] = 0.0;
+                    sc[0] = lsum;
+                    team_exchange(tot, sc, vec);
+                    lsum = sc[0];
                 }
             } else {
                 // (PMF_REGW16) eight waves' partials in flight at a time, sums in wave order
@@ -537,7 +686,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             }
         });
         PMF_STAMP(*this, 5);
-        if constexpr (NW > 1) {
+        if constexpr (NW > 1 && !WANT_F && !WANT_G) {
+            return 0.0;   // (the cached line search's q = T.d pass: predictions only, nothing to add up)
+        } else if constexpr (NW > 1) {
             T tot[NC];
 #pragma unroll
             for (int i = 0; i < NC; i++) tot[i] = (T)0;
@@ -545,7 +696,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             PMF_STAMP(*this, 6);
             double lsum = 0.0;
             if constexpr (WANT_F) lsum = wave_sum(lpart);
-            combine_waves(tot, lsum);
+            combine_waves(tot, lsum, WANT_G);
             PMF_STAMP(*this, 8);
             if constexpr (WANT_G) {
 #pragma unroll
@@ -565,7 +716,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
     // in every coordinate that prediction depends on (k = 1: always at alpha = max_step), where the snap-to-zero of the
     // trial point -- which the cached form does not see -- decides between log(0) and log(rounding residue); the caller
     // evaluates that trial directly instead.
-    __device__ __forceinline__ double logsum_cached(T alpha, bool& trusted) const
+    __device__ __forceinline__ double logsum_cached(T alpha, bool& trusted)
     {
         double lpart = 0.0;
         bool bad = false;
@@ -577,7 +728,46 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1> struct RegEval 
             lpart += on ? (double)xr[b] * d_log((double)pred) : 0.0;
         }
         trusted = __builtin_amdgcn_ballot_w64(bad) == 0;
-        return wave_sum(lpart);
+        double l = wave_sum(lpart);
+        if constexpr (NW > 1) {
+            // every wave of every member must take the same branch: an untrusted share poisons the sum
+            if (!trusted) l = __builtin_nan("");
+            T none[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) none[i] = (T)0;
+            combine_waves(none, l, false);
+            trusted = !(l != l);
+        }
+        return l;
+    }
+    // The same for LS_BATCH trial steps alpha, alpha decr, alpha decr^2, .. at once (teams: one exchange between CUs for what
+    // would be LS_BATCH of them; an Armijo search mostly ends within the first batch)
+    static constexpr int LS_BATCH = M_ > 1 ? TEAM_SC : 1;
+    __device__ __forceinline__ void logsum_cached_batch(T alpha, T decr, double (&ls)[LS_BATCH], bool (&trusted)[LS_BATCH])
+    {
+        if constexpr (M > 1) {
+            T al = alpha;
+#pragma unroll
+            for (int j = 0; j < LS_BATCH; j++) {
+                double lpart = 0.0;
+                bool bad = false;
+#pragma unroll
+                for (int b = 0; b < (CACHED ? NB : 0); b++) {
+                    const bool on = (unsigned)(64 * b + jlane) < nnz;
+                    const T pred = fma_t(al, qv[b], pv[b]);
+                    bad = bad || (on && !(pred > pv[b] * (T)1e-4));
+                    lpart += on ? (double)xr[b] * d_log((double)pred) : 0.0;
+                }
+                const double l = wave_sum(lpart);
+                ls[j] = __builtin_amdgcn_ballot_w64(bad) == 0 ? l : __builtin_nan("");
+                al *= decr;
+            }
+            combine_scalars(ls);
+#pragma unroll
+            for (int j = 0; j < LS_BATCH; j++) trusted[j] = !(ls[j] != ls[j]);
+        } else {
+            ls[0] = logsum_cached(alpha, trusted[0]);
+        }
     }
     __device__ __forceinline__ void advance_cached(T alpha)
     {

@@ -40,6 +40,22 @@
 
 namespace pmf {
 
+// ---- teams: one row over the register tiles of several CUs (reg_eval.hpp, M_ > 1) ------------------------------------------
+// For rows whose tile does not fit one CU's registers but does fit a few (k = 50 fp64, ~1000 nonzeros: 400 KB), where the
+// alternative is to stream the tile from L2 / HBM once per evaluation.  Workgroups of TEAM_NW waves, 28 or 32 steps each; the
+// partial gradients / log-likelihood sums of an evaluation cross CUs through tagged 8-byte granules in global memory.
+constexpr int TEAM_NW = 4, TEAM_M_MAX = 4;   // one wave per SIMD: CG's state next to a two-slot tile takes the 512 registers
+// layout of HalfArgs::team_buf, in 8-byte words: [0, 8) arrival counters per XCD, [8] error word, then TEAM_SLOTS teams of
+// TEAM_WORDS words: { mailbox[2], here[TEAM_M_MAX], exchange[2 parities][TEAM_M_MAX members][TEAM_GRAN granules] }
+constexpr unsigned TEAM_SLOTS_PER_XCD = 128, TEAM_SLOTS = 8 * TEAM_SLOTS_PER_XCD;
+constexpr int TEAM_SC = 4;                       // scalars per exchange (a line search asks for that many trial steps at once)
+constexpr unsigned TEAM_GRAN = 2 * 64 + 2 * TEAM_SC;   // one k-vector of <= 64 doubles and the scalars, as (low, high) halves
+constexpr unsigned TEAM_HEAD_WORDS = 16;
+constexpr unsigned TEAM_WORDS = 2 + TEAM_M_MAX + 2 * TEAM_M_MAX * TEAM_GRAN + 2;   // (+2: keeps teams 16-byte aligned)
+constexpr unsigned long long TEAM_BUF_BYTES = 8ull * (TEAM_HEAD_WORDS + (unsigned long long)TEAM_SLOTS * TEAM_WORDS);
+constexpr unsigned TEAM_SPIN_LIMIT = 1u << 20;   // polls (~1 us each) before a member gives the launch up
+
+
 // Optional phase timers (build with -DPMF_TIMING): per-wave shader-clock totals of the phases of row_eval,
 // added to a global array at kernel exit.  Slots: 0 gather, 1 phase 1, 2 coef/div, 3 phase 2, 4 combine, 5 whole kernel.
 #ifdef PMF_TIMING
@@ -163,6 +179,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     unsigned char* red_base;  // NW > 1: two sets of { [NW] partial log-likelihood sums, [NW][s_load] slots of partial gradients }
     int red_sel, red_bytes;   // the set the next combine_waves uses; bytes per set
     int wid;
+    static constexpr int member = 0;   // (teams exist in the register engine only)
     // launch constants
     const T* F;
     int k, ldF, s_load, s_stride, cap, tail;
@@ -712,6 +729,8 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     // (ref: src/poismf.c:191-193, src/nonnegcg.c:291-294).
     // `trusted` comes back false when some p_j + alpha q_j cancels to (almost) nothing (see RegEval::logsum_cached): the
     // caller then evaluates that trial directly.
+    static constexpr int LS_BATCH = 1;
+    __device__ __forceinline__ void logsum_cached_batch(T alpha, T, double (&ls)[1], bool (&trusted)[1]) const { ls[0] = logsum_cached(alpha, trusted[0]); }
     __device__ __forceinline__ double logsum_cached(T alpha, bool& trusted) const
     {
         double lpart = 0.0;

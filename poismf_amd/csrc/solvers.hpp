@@ -249,15 +249,25 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         const T dd = ev.dot(d, d);
         T step = max_step;
         bool accepted = false;
+        // (the log-likelihood terms of LS_BATCH consecutive trial steps come from one call: teams of CUs pay one exchange per
+        // call; the decisions are those of the one-at-a-time loop)
+        constexpr int LSB = EV::LS_BATCH;
+        double lsv[LSB];
+        bool lst[LSB];
         for (int ls = 0; ls < max_ls; ls++) {
+            if (ls % LSB == 0) ev.logsum_cached_batch(step, decr, lsv, lst);
             PMF_EW {
                 trial[i] = fma_t(step, d[i], x[i]);
                 trial[i] = ((double)trial[i] >= 1e-15) ? trial[i] : (T)0;
             }
             T r = ev.dot(bsum, trial);
             r += P.l2 * ev.dot(trial, trial);
-            bool trusted;
-            f_new = r - (T)ev.logsum_cached(step, trusted) * P.w;
+            double lsum_here = lsv[0];
+            bool trusted = lst[0];
+#pragma unroll
+            for (int j = 1; j < LSB; j++)
+                if (ls % LSB == j) { lsum_here = lsv[j]; trusted = lst[j]; }
+            f_new = r - (T)lsum_here * P.w;
             if (!trusted) f_new = fun_single(ev, P, bsum, trial);   // a prediction cancelled to ~0: evaluate at the snapped point
             if (!not_finite(f_new) && f_new <= f_cur - c_ls * step * dd) {
                 PMF_EW x[i] = trial[i];
