@@ -341,12 +341,14 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
                 // lane (jg, g) carries element jg of its NC (the four groups hold the same values); lanes 0 .. TEAM_SC - 1 a scalar each
                 const bool carrier = vec && jg < NC;
                 const bool scalar = lane < TEAM_SC;
+                // (opaque asm between the selects: left alone, the compiler turns each chain into a per-lane indexed load from
+                // a stack array -- scratch memory, or 48 KB of LDS when it promotes the array -- on the path of every exchange)
                 T mine = tot[0];
 #pragma unroll
-                for (int i = 1; i < NC; i++) mine = jg == i ? tot[i] : mine;
+                for (int i = 1; i < NC; i++) { mine = jg == i ? tot[i] : mine; asm volatile("" : "+v"(mine)); }
                 double mysc = sc[0];
 #pragma unroll
-                for (int j = 1; j < TEAM_SC; j++) mysc = lane == j ? sc[j] : mysc;
+                for (int j = 1; j < TEAM_SC; j++) { mysc = lane == j ? sc[j] : mysc; asm volatile("" : "+v"(mysc)); }
                 if (carrier) {
                     const unsigned long long b = __builtin_bit_cast(unsigned long long, (double)mine);
                     gran_store(slots + member * TEAM_GRAN + 2 * lane, (b & 0xffffffffull) | tag);
@@ -414,7 +416,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
             red_sel ^= 1;
             double mysc = sc[0];
 #pragma unroll
-            for (int j = 1; j < TEAM_SC; j++) mysc = lane == j ? sc[j] : mysc;
+            for (int j = 1; j < TEAM_SC; j++) { mysc = lane == j ? sc[j] : mysc; asm volatile("" : "+v"(mysc)); }
             if (lane < TEAM_SC) red_l[wid * TEAM_SC + lane] = mysc;
             __syncthreads();
 #pragma unroll

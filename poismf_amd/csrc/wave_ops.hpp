@@ -16,7 +16,9 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)
 // ---- raw lane movement on 32- and 64-bit payloads -------------------------------------------
 template <int CTRL> __device__ __forceinline__ int dpp_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+    // bound_ctrl: lanes without a source lane read 0 -- what `old` = 0 would give them too, but with every lane written the
+    // compiler needs no v_mov to set `old` up first (doubles: two of them per move, a seventh of the fp64 evaluation)
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v)
 {
