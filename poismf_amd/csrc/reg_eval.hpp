@@ -211,6 +211,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     T* qbuf;
     static constexpr bool CACHED = sizeof(T) == 8 && (NW_ == 1 || M_ > 1);   // compile-time: no trace of the cache in the other instances
     static constexpr bool MAY_CACHE = CACHED;
+    static constexpr bool CACHED_GRAD = CACHED;   // cg_row_cached may take gradients from the cached predictions
     T pv[CACHED ? NB : 1], qv[CACHED ? NB : 1];
 
     __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
@@ -648,7 +649,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     }
 
     // Same contract as RowEval::eval (store is not supported here: pq_cap == 0)
-    template <bool WANT_F, bool WANT_G> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
+    // FROM_CACHE: the predictions are those kept in pv (p = T.x, advanced by the accepted step): no dots, no butterfly --
+    // the backward half of a pass only
+    template <bool WANT_F, bool WANT_G, bool FROM_CACHE = false> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
     {
         n_eval++;
         PMF_STAMP(*this, 0);
@@ -659,12 +662,16 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             constexpr int n = (S - G * b) < G ? (S - G * b) : G;
-            T p[G];
+            T pred;
+            if constexpr (FROM_CACHE && CACHED) pred = pv[b];
+            else {
+                T p[G];
 #pragma unroll
-            for (int u = 0; u < G; u++) p[u] = u < n ? lane_dot(t[(G * b + u) < S ? (G * b + u) : 0]) : (T)0;
-            if constexpr (b == 0) PMF_STAMP(*this, 1);
-            const T pred = transpose_sum<n>(p);
-            if constexpr (b == 0) PMF_STAMP(*this, 2);
+                for (int u = 0; u < G; u++) p[u] = u < n ? lane_dot(t[(G * b + u) < S ? (G * b + u) : 0]) : (T)0;
+                if constexpr (b == 0) PMF_STAMP(*this, 1);
+                pred = transpose_sum<n>(p);
+                if constexpr (b == 0) PMF_STAMP(*this, 2);
+            }
             if constexpr (CACHED) {
                 if (store == pbuf) pv[b] = pred;
                 else if (store == qbuf) qv[b] = pred;

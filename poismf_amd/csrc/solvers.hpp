@@ -204,17 +204,28 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
     int nfeval = 1;
     if (not_finite(f_cur)) return;
 
+    bool p_current = false;   // the cached p is T.x for the current x, to rounding (advanced by a step the cache could be trusted for)
+    auto grad_pass = [&](T (&gg)[NC]) {
+        if constexpr (EV::CACHED_GRAD) {
+            if (p_current) {
+                ev.template eval<false, true, true>((T)-1, gg);
+                return;
+            }
+        }
+        ev.template eval<false, true>((T)-1, gg, ev.pbuf);
+    };
     for (int it = 0; it < maxiter; it++) {
         if (it > 0) {
-            // gradient at x: coefficients from the cached p = T.x are not used -- the pass recomputes F_j . x (and
-            // refreshes p with the exact values, undoing the rounding of p += alpha q)
+            // gradient at x.  Register engine: after a trusted step the coefficients x_j / p_j come from the cached
+            // p = T.x + alpha T.d -- the backward half of a pass; differs from fresh dot products by rounding only, and p is at
+            // most `maxupd` updates away from exact values.  Otherwise the pass recomputes F_j . x and refreshes p.
             ev.set_point(x);
             if (!weighted) {
                 PMF_EW g[i] = fma_t(two_l2, x[i], bsum[i]);
-                ev.template eval<false, true>((T)-1, g, ev.pbuf);
+                grad_pass(g);
             } else {
                 PMF_EW g[i] = (T)0;
-                ev.template eval<false, true>((T)-1, g, ev.pbuf);
+                grad_pass(g);
                 PMF_EW {
                     g[i] = g[i] * P.w;
                     g[i] = g[i] + bsum[i];
@@ -272,13 +283,15 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
             if (!not_finite(f_new) && f_new <= f_cur - c_ls * step * dd) {
                 PMF_EW x[i] = trial[i];
                 accepted = true;
+                p_current = trusted;
+                if constexpr (EV::CACHED_GRAD) { if (trusted) ev.advance_cached(step); }
                 break;
             }
             nfeval++;
             if (nfeval >= maxnfeval) return;
             step *= decr;
         }
-        (void)accepted;  // p = T.x is recomputed exactly by the next gradient pass
+        if (!accepted) p_current = false;   // (x did not move, but the cache may hold a refused trial's history: recompute)
         f_cur = f_new;
         gprev_sq = ev.dot(g, g);
         PMF_EW { gp[i] = g[i]; dp[i] = d[i]; }
