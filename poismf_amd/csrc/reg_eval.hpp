@@ -751,7 +751,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     }
     // The same for LS_BATCH trial steps alpha, alpha decr, alpha decr^2, .. at once (teams: one exchange between CUs for what
     // would be LS_BATCH of them; an Armijo search mostly ends within the first batch)
-    static constexpr int LS_BATCH = M_ > 1 ? TEAM_SC : 1;
+#ifndef PMF_TEAM_LSB
+#define PMF_TEAM_LSB 4
+#endif
+    static constexpr int LS_BATCH = M_ > 1 ? PMF_TEAM_LSB : 1;
     __device__ __forceinline__ void logsum_cached_batch(T alpha, T decr, double (&ls)[LS_BATCH], bool (&trusted)[LS_BATCH])
     {
         if constexpr (M > 1) {
@@ -771,9 +774,12 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
                 ls[j] = __builtin_amdgcn_ballot_w64(bad) == 0 ? l : __builtin_nan("");
                 al *= decr;
             }
-            combine_scalars(ls);
+            double sc[TEAM_SC];
 #pragma unroll
-            for (int j = 0; j < LS_BATCH; j++) trusted[j] = !(ls[j] != ls[j]);
+            for (int j = 0; j < TEAM_SC; j++) sc[j] = j < LS_BATCH ? ls[j < LS_BATCH ? j : 0] : 0.0;
+            combine_scalars(sc);
+#pragma unroll
+            for (int j = 0; j < LS_BATCH; j++) { ls[j] = sc[j]; trusted[j] = !(ls[j] != ls[j]); }
         } else {
             ls[0] = logsum_cached(alpha, trusted[0]);
         }
