@@ -38,10 +38,14 @@ def plan_of(csr, csc, A0, B0, k, which=1):
     return txt
 
 
+NO_TEAMS = any(os.environ.get(k) for k in ("POISMF_HIP_NO_TEAM", "POISMF_HIP_NO_REGTILE", "POISMF_HIP_STATIC_ROWS"))   # scripts/knob_matrix.sh
+
+
 @pytest.mark.parametrize("shape", list(SHAPES))
 def test_each_team_shape_vs_oracle(shape):
     csr, csc, A0, B0 = ragged_problem(SHAPES[shape], 6000, 50, False, seed=5)
-    assert f"half_sweep_team_kernel<double,cg,{shape}>" in plan_of(csr, csc, A0, B0, 50)
+    if not NO_TEAMS:
+        assert f"half_sweep_team_kernel<double,cg,{shape}>" in plan_of(csr, csc, A0, B0, 50)
     A, B, args = gpu_run(csr, csc, A0, B0, "cg", 2, 50)
     Ar, Br = oracle_run(False, csr, csc, A0, B0, "cg", args)
     compare(False, "cg", csr, args, A, B, Ar, Br, converged=False)
