@@ -37,6 +37,9 @@ template <int I, int N, class Fn> __device__ __forceinline__ void static_for(Fn&
     }
 }
 
+#ifndef PMF_BCAST64_DPP
+#define PMF_BCAST64_DPP 1
+#endif
 // value of lane U of the caller's group of G lanes (ds_swizzle, bit-mask mode inside each half-wave:
 // src = (lane & ~(G - 1)) | U)
 template <int G, int U> __device__ __forceinline__ int group_bcast_i32(int v)
@@ -50,6 +53,9 @@ template <int G, int U> __device__ __forceinline__ float group_bcast(float v)
 }
 template <int G, int U> __device__ __forceinline__ double group_bcast(double v)
 {
+    // sixteen lanes are one DPP row: v_mov_b64_dpp row_newbcast (the one DPP control 64-bit operands take) instead of two trips
+    // through the LDS crossbar -- the fp64 kernels run one wave per SIMD and wait every such trip out
+    if constexpr (G == 16 && PMF_BCAST64_DPP) return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + U, 0xf, 0xf, true);
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = (unsigned)group_bcast_i32<G, U>((int)(unsigned)b);
     const unsigned hi = (unsigned)group_bcast_i32<G, U>((int)(unsigned)(b >> 32));
