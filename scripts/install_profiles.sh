@@ -4,7 +4,9 @@
 set -e
 cd "$(dirname "$0")/.."
 SRC=gpurun_out/$1; DST=profiles/${2:-r02}
+KEEP=$(mktemp -d); [ -d $DST/run_config ] && cp -r $DST/run_config $KEEP/   # (scripts/run_config.py's records live there too)
 rm -rf $DST; mkdir -p $DST/pmc
+[ -d $KEEP/run_config ] && cp -r $KEEP/run_config $DST/; rm -rf $KEEP
 cp $SRC/bench_line.json $DST/bench_line.json
 for n in pg10 pg1 cg64; do
   cp $SRC/kt_$n/kt_kernel_stats.csv $DST/kt_${n}_kernel_stats.csv
