@@ -133,12 +133,16 @@ int regw_steps_for(unsigned max_nnz, int nw)
 // Two CUs where they hold the row; the 28-step instance (no scratch) where three are needed anyway.
 // Below TEAM_MIN_NNZ a row's tile (k = 50 fp64: 400 B per nonzero) is resident in one CU's LDS: the LDS engine keeps it.
 constexpr unsigned TEAM_MIN_NNZ = 385;
+#ifndef PMF_TEAM_S36
+#define PMF_TEAM_S36 1
+#endif
 struct TeamShape { int members, steps; };
 inline TeamShape team_shape_for(unsigned max_nnz)
 {
     const unsigned per_step = (unsigned)(REG_JG * TEAM_NW);
     if (max_nnz < TEAM_MIN_NNZ) return { 0, 0 };
     if (max_nnz <= 2u * 32u * per_step) return { 2, 32 };
+    if (PMF_TEAM_S36 && max_nnz <= 2u * 36u * per_step) return { 2, 36 };
     if (max_nnz <= 3u * 28u * per_step) return { 3, 28 };
     if (max_nnz <= 3u * 32u * per_step) return { 3, 32 };
     if (max_nnz <= 4u * 32u * per_step) return { 4, 32 };

@@ -242,10 +242,12 @@ template <class T, int METHOD, int S, int G, int NS>
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(reg_waves(4 * S * NS, METHOD)))) void half_sweep_reg_kernel(const HalfArgs<T> a)
 {
     RegEval<T, S, G, NS> ev;
+    constexpr int SMEM = RegEval<T, S, G, NS>::SMEM_BYTES;   // (only CG on doubles parks k-vectors here)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM > 0 && METHOD == K_CG ? SMEM : 16];
 #ifdef PMF_TIMING
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
 #endif
-    sweep_rows<RegEval<T, S, G, NS>, T, RegEval<T, S, G, NS>::NC, METHOD, 1>(a, ev, nullptr);
+    sweep_rows<RegEval<T, S, G, NS>, T, RegEval<T, S, G, NS>::NC, METHOD, 1>(a, ev, smem);
 #ifdef PMF_TIMING
     if (ev.lane == 0) atomicAdd(&g_pmf_timing[5], __builtin_amdgcn_s_memtime() - t_kernel);
 #endif
@@ -558,6 +560,7 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
     t_device = o.device; t_num_cu = o.num_cu;
     if (o.team > 1) {
         if (o.team == 2 && o.reg_S == 32) return launch_team<2, 32>(o.main_stream, method, a);
+        if constexpr (PMF_TEAM_S36) { if (o.team == 2 && o.reg_S == 36) return launch_team<2, 36>(o.main_stream, method, a); }
         if (o.team == 3 && o.reg_S == 28) return launch_team<3, 28>(o.main_stream, method, a);
         if (o.team == 3 && o.reg_S == 32) return launch_team<3, 32>(o.main_stream, method, a);
         if (o.team == 4 && o.reg_S == 32) return launch_team<4, 32>(o.main_stream, method, a);

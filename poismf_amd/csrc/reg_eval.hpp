@@ -172,7 +172,15 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     // one set of cross-wave scratch: NW partial k-vectors and NW scalars (teams: NW x TEAM_SC scalars)
     static constexpr int RED_BYTES = NW_ * KP * (int)sizeof(T) + (M_ > 1 ? NW_ * 8 * TEAM_SC : 16 * ((NW_ * 8 + 15) / 16));
     static constexpr int TEAM_BYTES = M_ > 1 ? KP * (int)sizeof(T) + 8 * TEAM_SC : 0;           // team totals: a k-vector and the scalars
-    static constexpr int SMEM_BYTES = (NW_ > 1 ? 2 * RED_BYTES + 16 : 0) + TEAM_BYTES;
+    // PARKS: six k-vectors per wave wait in LDS during the passes of cg_row_cached (solvers.hpp)
+#ifndef PMF_PARK
+#define PMF_PARK 1
+#endif
+    static constexpr bool PARKS = PMF_PARK && sizeof(T) == 8 && M_ > 1;
+    static constexpr int PARK_SLOTS = 6;
+    static constexpr int PARK_BYTES = PARKS ? NW_ * PARK_SLOTS * KP * (int)sizeof(T) : 0;
+    static constexpr int PARK_OFFSET = (NW_ > 1 ? 2 * RED_BYTES + 16 : 0) + TEAM_BYTES;
+    static constexpr int SMEM_BYTES = PARK_OFFSET + PARK_BYTES;
     static_assert(M_ == 1 || (sizeof(T) == 8 && NW_ > 1 && NS_ * Slot<T>::N <= WAVE / G_), "teams: doubles, one element per group to publish");
     static_assert(G == 8 || G == 16, "a factor row is held by 8 or 16 lanes");
 
@@ -202,6 +210,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
     int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
     unsigned* ticket_word;
+    T* park_base;                     // PARKS: this wave's PARK_SLOTS k-vectors in LDS
     // team state (M > 1)
     unsigned long long* team_words;   // this team's words of HalfArgs::team_buf
     unsigned* team_err;               // != 0: some exchange of this launch timed out, give up
@@ -227,6 +236,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
         red_sel = 0;
         ticket_word = (unsigned*)(smem + 2 * RED_BYTES);
         team_tot = (T*)(smem + 2 * RED_BYTES + 16);
+        park_base = (T*)(smem + PARK_OFFSET) + (NW > 1 ? (int)(threadIdx.x / WAVE) : 0) * PARK_SLOTS * KP;
         member = 0; xseq = 0; team_words = nullptr; team_err = nullptr;
         F = F_;
         k = geo.k; ldF = geo.ldF; s_load = geo.s_load; zero_row = geo.zero_row;
@@ -297,6 +307,30 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
                         if (act[n * SN + e]) p[elem[n * SN + e]] = x[n * SN + e];
                 }
             }
+        }
+    }
+
+    // a k-vector to / from this wave's LDS slot (the four groups hold the same values: one writes, all read)
+    __device__ __forceinline__ void park(int slot, const T (&x)[NC])
+    {
+        if (jg == 0) {
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                SA v;
+#pragma unroll
+                for (int e = 0; e < SN; e++) v.v[e] = x[n * SN + e];
+                *(SA*)(park_base + slot * KP + (g + G * n) * SN) = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void unpark(int slot, T (&x)[NC])
+    {
+        wave_lds_fence();
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            const SA v = *(const SA*)(park_base + slot * KP + (g + G * n) * SN);
+#pragma unroll
+            for (int e = 0; e < SN; e++) x[n * SN + e] = v.v[e];
         }
     }
 

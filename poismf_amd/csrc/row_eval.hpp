@@ -729,6 +729,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     // (ref: src/poismf.c:191-193, src/nonnegcg.c:291-294).
     // `trusted` comes back false when some p_j + alpha q_j cancels to (almost) nothing (see RegEval::logsum_cached): the
     // caller then evaluates that trial directly.
+    static constexpr bool PARKS = false;
     static constexpr bool CACHED_GRAD = false;
     static constexpr int LS_BATCH = 1;
     __device__ __forceinline__ void logsum_cached_batch(T alpha, T, double (&ls)[1], bool (&trusted)[1]) const { ls[0] = logsum_cached(alpha, trusted[0]); }

@@ -180,23 +180,34 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
     const int maxnfeval = 150, max_ls = 20;
     const int maxiter = P.maxupd > 0 ? P.maxupd : 0x7fffffff;
     const T two_l2 = (T)(2. * (double)P.l2);
-    T g[NC], d[NC], gp[NC], dp[NC], trial[NC], dummy[NC];
-    PMF_EW { gp[i] = (T)0; dp[i] = (T)0; dummy[i] = (T)0; }
+    T g[NC], d[NC], gp[NC], dp[NC], trial[NC], dummy[NC], gz[NC], bs[NC];
+    PMF_EW { gp[i] = (T)0; dp[i] = (T)0; dummy[i] = (T)0; g[i] = (T)0; d[i] = (T)0; bs[i] = bsum[i]; }
     T gprev_sq = (T)0;
+    // PARKS (fp64 register engine): the k-vectors that must survive a pass over the tile wait in LDS meanwhile (slots 0 x,
+    // 1 g, 2 d, 3 previous g, 4 previous d, 5 the constant term), so that the pass has the architectural registers to itself
+    // and the tile need not sit in AGPRs, copied out for each use.  The pass's own contribution comes back in gz and is
+    // added afterwards (0 + sum, then base + that: the bits of accumulating onto the base).
+    constexpr bool PK = EV::PARKS;
 
     // f0 = f(x) and the first gradient from ONE pass over the row (both are evaluated at x; the reference computes
     // f0 first, ref: src/nonnegcg.c:191, and returns before the gradient if it is not finite -- same outcome), keeping
     // p = T.x on the way
     ev.set_point(x);
-    T reg = ev.dot(bsum, x);
+    T reg = ev.dot(bs, x);
     reg += P.l2 * ev.dot(x, x);
-    if (!weighted) { PMF_EW g[i] = fma_t(two_l2, x[i], bsum[i]); }
-    else { PMF_EW g[i] = (T)0; }
-    T f_cur = reg - (T)ev.template eval<true, true>((T)-1, g, ev.pbuf) * P.w;
-    if (weighted) {
+    PMF_EW gz[i] = (T)0;
+    if constexpr (PK) { ev.park(0, x); ev.park(5, bs); }
+    T f_cur = reg - (T)ev.template eval<true, true>((T)-1, gz, ev.pbuf) * P.w;
+    if constexpr (PK) { ev.unpark(0, x); ev.unpark(5, bs); }
+    if (!weighted) {
         PMF_EW {
-            g[i] = g[i] * P.w;
-            g[i] = g[i] + bsum[i];
+            g[i] = fma_t(two_l2, x[i], bs[i]);
+            g[i] = g[i] + gz[i];
+        }
+    } else {
+        PMF_EW {
+            g[i] = gz[i] * P.w;
+            g[i] = g[i] + bs[i];
             g[i] = fma_t(two_l2, x[i], g[i]);
         }
     }
@@ -220,15 +231,19 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
             // p = T.x + alpha T.d -- the backward half of a pass; differs from fresh dot products by rounding only, and p is at
             // most `maxupd` updates away from exact values.  Otherwise the pass recomputes F_j . x and refreshes p.
             ev.set_point(x);
+            PMF_EW gz[i] = (T)0;
+            if constexpr (PK) { ev.park(0, x); ev.park(5, bs); }
+            grad_pass(gz);
+            if constexpr (PK) { ev.unpark(0, x); ev.unpark(5, bs); ev.unpark(3, gp); ev.unpark(4, dp); }
             if (!weighted) {
-                PMF_EW g[i] = fma_t(two_l2, x[i], bsum[i]);
-                grad_pass(g);
-            } else {
-                PMF_EW g[i] = (T)0;
-                grad_pass(g);
                 PMF_EW {
-                    g[i] = g[i] * P.w;
-                    g[i] = g[i] + bsum[i];
+                    g[i] = fma_t(two_l2, x[i], bs[i]);
+                    g[i] = g[i] + gz[i];
+                }
+            } else {
+                PMF_EW {
+                    g[i] = gz[i] * P.w;
+                    g[i] = g[i] + bs[i];
                     g[i] = fma_t(two_l2, x[i], g[i]);
                 }
             }
@@ -255,7 +270,9 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
 
         // q = T.d (second and last pass over the tile in this iteration)
         ev.set_point(d);
+        if constexpr (PK) { ev.park(0, x); ev.park(5, bs); ev.park(1, g); ev.park(2, d); }
         (void)ev.template eval<false, false>((T)0, dummy, ev.qbuf);
+        if constexpr (PK) { ev.unpark(0, x); ev.unpark(5, bs); ev.unpark(1, g); ev.unpark(2, d); }
 
         const T dd = ev.dot(d, d);
         T step = max_step;
@@ -271,7 +288,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
                 trial[i] = fma_t(step, d[i], x[i]);
                 trial[i] = ((double)trial[i] >= 1e-15) ? trial[i] : (T)0;
             }
-            T r = ev.dot(bsum, trial);
+            T r = ev.dot(bs, trial);
             r += P.l2 * ev.dot(trial, trial);
             double lsum_here = lsv[0];
             bool trusted = lst[0];
@@ -279,7 +296,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
             for (int j = 1; j < LSB; j++)
                 if (ls % LSB == j) { lsum_here = lsv[j]; trusted = lst[j]; }
             f_new = r - (T)lsum_here * P.w;
-            if (!trusted) f_new = fun_single(ev, P, bsum, trial);   // a prediction cancelled to ~0: evaluate at the snapped point
+            if (!trusted) f_new = fun_single(ev, P, bs, trial);   // a prediction cancelled to ~0: evaluate at the snapped point
             if (!not_finite(f_new) && f_new <= f_cur - c_ls * step * dd) {
                 PMF_EW x[i] = trial[i];
                 accepted = true;
@@ -294,7 +311,8 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         if (!accepted) p_current = false;   // (x did not move, but the cache may hold a refused trial's history: recompute)
         f_cur = f_new;
         gprev_sq = ev.dot(g, g);
-        PMF_EW { gp[i] = g[i]; dp[i] = d[i]; }
+        if constexpr (PK) { ev.park(3, g); ev.park(4, d); }
+        else { PMF_EW { gp[i] = g[i]; dp[i] = d[i]; } }
     }
 }
 

@@ -1,7 +1,7 @@
 """Rows shared by a TEAM of CUs (poismf_amd/csrc/reg_eval.hpp, M_ > 1; poismf_hip.hip, half_sweep_team_kernel): CG on doubles
 with two 16-byte slots per lane (k = 33 .. 64), rows of 385 .. 2048 nonzeros -- the item rows of BASELINE config C3.  Through
-the C-ABI against the oracle: lengths on both sides of every team shape (2 x 32 steps up to 1024, 3 x 28 up to 1344, 3 x 32 up
-to 1536, 4 x 32 up to 2048, streamed beyond), both line-search modes, the weighted objective (column sums of the tile cross
+the C-ABI against the oracle: lengths on both sides of every team shape (2 x 32 steps up to 1024, 2 x 36 up to 1152, 3 x 28 up to
+1344, 3 x 32 up to 1536, 4 x 32 up to 2048, streamed beyond), both line-search modes, the weighted objective (column sums of the tile cross
 the team too), and agreement with the streamed path on the same input.  Needs an MI355X."""
 import os
 import subprocess
@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # rows above 1024 nonzeros share one length class (powers of two there), and a class takes the shape its longest row needs
 SHAPES = {
     "S=32,NW=4,M=2": [384, 385, 386, 511, 512, 513, 700, 1000, 1023, 1024],
-    "S=28,NW=4,M=3": [1025, 1100, 1200, 1343, 1344],
+    "S=36,NW=4,M=2": [1025, 1100, 1151, 1152],
+    "S=28,NW=4,M=3": [1025, 1153, 1200, 1343, 1344],
     "S=32,NW=4,M=3": [1025, 1345, 1500, 1535, 1536],
     "S=32,NW=4,M=4": [1025, 1537, 1800, 2047, 2048, 2049, 2300],
 }
