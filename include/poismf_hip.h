@@ -178,7 +178,10 @@ POISMF_HIP_API real_t *poismf_hip_session_A(poismf_hip_session *s);
 POISMF_HIP_API real_t *poismf_hip_session_B(poismf_hip_session *s);
 POISMF_HIP_API void poismf_hip_session_factors_dirty(poismf_hip_session *s, int which);
 
-/* Host <-> device copies of the full factors (synchronous with respect to the session stream). */
+/* Host <-> device copies of the full factors (synchronous with respect to the session stream).
+ * get_factors (like run_poismf and poismf_hip_session_run) also returns 1 when a half-sweep since the last check lost a
+ * row launch that shares rows between CUs (fp64 CG, 385-2048 nonzeros; the kernels give up after ~1 s without an answer
+ * from a team member instead of hanging the device): the factors are then not to be used. */
 POISMF_HIP_API int poismf_hip_session_set_factors(poismf_hip_session *s, const real_t *A_host, const real_t *B_host);
 POISMF_HIP_API int poismf_hip_session_get_factors(poismf_hip_session *s, real_t *A_host, real_t *B_host);
 
