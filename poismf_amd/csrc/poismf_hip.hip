@@ -392,6 +392,15 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
         ev.probe_wait = 0;
 #endif
         ev.begin_row(a.indices + p0, a.values + p0, nnz);
+#ifdef PMF_PROBE
+        {   // the tile has arrived when a value that depends on every load has
+            T probe_sum[NC];
+            PMF_EW probe_sum[i] = (T)0;
+            ev.tile_touch(probe_sum);
+            ev.probe_acc[4] += __builtin_amdgcn_s_memtime() - t_row0;
+            if (probe_sum[0] == (T)123.456) ev.probe_acc[6]++;
+        }
+#endif
         solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d.lrow), nnz);
 #ifdef PMF_PROBE
         // (a probe build leaves the per-row counters to the stamps) low half: cycles / 256 spent waiting for the team, high half: of the whole row
@@ -399,9 +408,18 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
             a.eval_rows[uniform(d.lrow)] = (unsigned)std::min<unsigned long long>(0xffffu, ev.probe_wait >> 8) |
                                            ((unsigned)std::min<unsigned long long>(0xffffu, (__builtin_amdgcn_s_memtime() - t_row0) >> 8) << 16);
 #endif
+#ifdef PMF_PROBE
+        ev.probe_acc[5] += __builtin_amdgcn_s_memtime() - t_row0;
+        ev.probe_acc[6] += ev.probe_wait;
+#endif
         rowno++;
         t = t_next;
     }
+#ifdef PMF_PROBE
+    // kernel-wide sums of the first members' wave 0
+    if (threadIdx.x == 0 && ev.member == 0)
+        for (int q = 0; q < 8; q++) atomicAdd(a.team_buf + 8 + q, ev.probe_acc[q]);   // (free words of the head; last team launch wins)
+#endif
 }
 
 namespace {

@@ -1073,6 +1073,12 @@ int poismf_hip_session_topn(poismf_hip_session* s, size_t user, const sparse_ix*
 }
 
 #ifdef PMF_PROBE
+// development only: the head words of the team buffer (a -DPMF_PROBE build sums phase cycles of the last team launch in [8, 16))
+extern "C" __attribute__((visibility("default"))) int poismf_hip_debug_team_head(poismf_hip_session* s, unsigned long long* out)
+{
+    if (s->d_team == nullptr) return 1;
+    return pmf_download(out, s->d_team, 8 * TEAM_HEAD_WORDS, s->stream) != hipSuccess;
+}
 // development only (not in the header): the raw per-row counters of half `which`, which a -DPMF_PROBE build fills with stamps
 extern "C" __attribute__((visibility("default"))) int poismf_hip_debug_eval_rows(poismf_hip_session* s, int which, unsigned* out, size_t n)
 {

@@ -206,6 +206,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
 #ifdef PMF_PROBE
     unsigned* probe = nullptr;
     unsigned long long probe_wait = 0;   // teams: cycles wave 0 spent polling the other members' granules
+    unsigned long long probe_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // teams: cycles per phase, summed over the kernel (probe_team.py)
 #endif
     unsigned char* red_base;  // NW > 1: two sets of { [NW][KP] partial gradients, [NW] partial log-likelihood sums }
     int red_sel;              // the set the next combine_waves uses (alternating sets: one barrier per evaluation)
@@ -325,6 +326,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     }
     __device__ __forceinline__ void unpark(int slot, T (&x)[NC])
     {
+#ifdef PMF_PROBE
+        const unsigned long long t_up0 = __builtin_amdgcn_s_memtime();
+        struct UpTimer { unsigned long long& acc; unsigned long long t0; __device__ ~UpTimer() { acc += __builtin_amdgcn_s_memtime() - t0; } } up_timer{ probe_acc[3], t_up0 };
+#endif
         wave_lds_fence();
 #pragma unroll
         for (int n = 0; n < NS; n++) {
@@ -695,6 +700,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     {
         n_eval++;
         PMF_STAMP(*this, 0);
+#ifdef PMF_PROBE
+        const unsigned long long t_eval0 = __builtin_amdgcn_s_memtime();
+        struct EvalTimer { unsigned long long& acc; unsigned long long t0; __device__ ~EvalTimer() { acc += __builtin_amdgcn_s_memtime() - t0; } } eval_timer{ probe_acc[0], t_eval0 };
+#endif
         double lpart = 0.0;
         T part[NC];
 #pragma unroll
@@ -745,7 +754,13 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
             PMF_STAMP(*this, 6);
             double lsum = 0.0;
             if constexpr (WANT_F) lsum = wave_sum(lpart);
+#ifdef PMF_PROBE
+            const unsigned long long t_cw0 = __builtin_amdgcn_s_memtime();
+#endif
             combine_waves(tot, lsum, WANT_G);
+#ifdef PMF_PROBE
+            probe_acc[1] += __builtin_amdgcn_s_memtime() - t_cw0;
+#endif
             PMF_STAMP(*this, 8);
             if constexpr (WANT_G) {
 #pragma unroll
@@ -798,6 +813,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     __device__ __forceinline__ void logsum_cached_batch(T alpha, T decr, double (&ls)[LS_BATCH], bool (&trusted)[LS_BATCH])
     {
         if constexpr (M > 1) {
+#ifdef PMF_PROBE
+            const unsigned long long t_ls0 = __builtin_amdgcn_s_memtime();
+            struct LsTimer { unsigned long long& acc; unsigned long long t0; __device__ ~LsTimer() { acc += __builtin_amdgcn_s_memtime() - t0; } } ls_timer{ probe_acc[2], t_ls0 };
+#endif
             T al = alpha;
 #pragma unroll
             for (int j = 0; j < LS_BATCH; j++) {
@@ -817,7 +836,13 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
             double sc[TEAM_SC];
 #pragma unroll
             for (int j = 0; j < TEAM_SC; j++) sc[j] = j < LS_BATCH ? ls[j < LS_BATCH ? j : 0] : 0.0;
+#ifdef PMF_PROBE
+            const unsigned long long t_cs0 = __builtin_amdgcn_s_memtime();
+#endif
             combine_scalars(sc);
+#ifdef PMF_PROBE
+            probe_acc[7] += __builtin_amdgcn_s_memtime() - t_cs0;
+#endif
 #pragma unroll
             for (int j = 0; j < LS_BATCH; j++) { ls[j] = sc[j]; trusted[j] = !(ls[j] != ls[j]); }
         } else {
@@ -830,6 +855,14 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
         for (int b = 0; b < (CACHED ? NB : 0); b++) pv[b] = fma_t(alpha, qv[b], pv[b]);
     }
 
+#ifdef PMF_PROBE
+    // a value that depends on every register of the tile (the probe's "the gather has landed")
+    __device__ __forceinline__ void tile_touch(T (&acc)[NC])
+    {
+#pragma unroll
+        for (int s = 0; s < S; s++) acc[0] += t[s][0].v[0] + t[s][NS - 1].v[SN - 1];
+    }
+#endif
     // acc_c += sum_j F[ind_j, c]  (adjustment_Bsum's gather pass, ref: src/poismf.c:108-110)
     __device__ __forceinline__ void tile_colsum(T (&acc)[NC])
     {
