@@ -339,59 +339,58 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
         }
     }
 
-    // rows: number 1, 2, ..; the ticket of row number i travels in mailbox slot i % 2
-    unsigned rowno = 1, t = 0;
-    if (ev.member == 0) {
-        if (threadIdx.x == 0) {
-            box[0] = atomicAdd(a.queue, 1u);
-            gran_store(mail + 1, ((unsigned long long)1u << 32) | (box[0] < a.nrows ? box[0] : END));
-        }
-        __syncthreads();
-        t = uniform(box[0]);
-        __syncthreads();
-    }
-    for (;;) {
-        unsigned t_next = 0;
+    // rows: number 1, 2, ..; the ticket of row number i travels in mailbox slot i % 2.  Every member learns row i + 1's ticket
+    // right after requesting row i's tile and fetches that row's indices while the solver runs (fetch_meta / gather, as the
+    // single-workgroup kernels do in sweep_rows), so a row costs one trip to memory on the critical path, not three.
+    auto next_ticket = [&](unsigned rowno_next) -> unsigned {     // (call with all threads)
         if (ev.member == 0) {
-            // the next row's ticket goes out now: the others find it waiting when they finish this row
-            if (t < a.nrows) {
-                if (threadIdx.x == 0) {
-                    box[0] = atomicAdd(a.queue, 1u);
-                    gran_store(mail + ((rowno + 1) & 1u), ((unsigned long long)(rowno + 1) << 32) | (box[0] < a.nrows ? box[0] : END));
-                }
-                __syncthreads();
-                t_next = uniform(box[0]);
-                __syncthreads();
-            }
-        } else {
             if (threadIdx.x == 0) {
-                unsigned long long v = 0;
-                for (unsigned spins = 0;; spins++) {
-                    v = gran_load(mail + (rowno & 1u));
-                    if ((unsigned)(v >> 32) == rowno) break;
-                    if (spins > TEAM_SPIN_LIMIT || ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v = END;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                box[0] = (unsigned)v;
+                box[0] = atomicAdd(a.queue, 1u);
+                gran_store(mail + (rowno_next & 1u), ((unsigned long long)rowno_next << 32) | (box[0] < a.nrows ? box[0] : END));
             }
-            __syncthreads();
-            t = uniform(box[0]);
-            __syncthreads();
+        } else if (threadIdx.x == 0) {
+            unsigned long long v = 0;
+            for (unsigned spins = 0;; spins++) {
+                v = gran_load(mail + (rowno_next & 1u));
+                if ((unsigned)(v >> 32) == rowno_next) break;
+                if (spins > TEAM_SPIN_LIMIT || ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = END;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            box[0] = (unsigned)v;
         }
-        if (t >= a.nrows) break;
+        __syncthreads();
+        const unsigned tk = uniform(box[0]);
+        __syncthreads();
+        return tk;
+    };
+    auto row_of = [&](unsigned tk, unsigned& nnz, unsigned long long& p0, unsigned& lrow) {
+        const RowDesc d = desc[tk < a.nrows ? tk : 0u];
+        nnz = uniform(d.nnz);
+        p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
+        lrow = uniform(d.lrow);
+    };
+    unsigned rowno = 1;
+    unsigned t = next_ticket(1);
+    unsigned nnz = 0, lrow = 0;
+    unsigned long long p0 = 0;
+    row_of(t, nnz, p0, lrow);
+    if (t < a.nrows) ev.fetch_meta(a.indices + p0, nnz);
+    while (t < a.nrows) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        const RowDesc d = desc[t];
-        const unsigned nnz = uniform(d.nnz);
-        const unsigned long long p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
 #ifdef PMF_PROBE
         const unsigned long long t_row0 = __builtin_amdgcn_s_memtime();
         ev.probe_wait = 0;
 #endif
-        ev.begin_row(a.indices + p0, a.values + p0, nnz);
+        ev.gather(a.values + p0, nnz);                               // the indices are here: request the tile
+        const unsigned t_next = next_ticket(rowno + 1);
+        unsigned nnz_next = 0, lrow_next = 0;
+        unsigned long long p0_next = 0;
+        row_of(t_next, nnz_next, p0_next, lrow_next);
+        if (t_next < a.nrows) ev.fetch_meta(a.indices + p0_next, nnz_next);
 #ifdef PMF_PROBE
         {   // the tile has arrived when a value that depends on every load has
             T probe_sum[NC];
@@ -401,19 +400,17 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
             if (probe_sum[0] == (T)123.456) ev.probe_acc[6]++;
         }
 #endif
-        solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d.lrow), nnz);
+        solve_row<EV, T, NC, METHOD>(a, ev, bs, lrow, nnz);
 #ifdef PMF_PROBE
         // (a probe build leaves the per-row counters to the stamps) low half: cycles / 256 spent waiting for the team, high half: of the whole row
         if (a.eval_rows != nullptr && threadIdx.x == 0 && ev.member == 0)
-            a.eval_rows[uniform(d.lrow)] = (unsigned)std::min<unsigned long long>(0xffffu, ev.probe_wait >> 8) |
-                                           ((unsigned)std::min<unsigned long long>(0xffffu, (__builtin_amdgcn_s_memtime() - t_row0) >> 8) << 16);
-#endif
-#ifdef PMF_PROBE
+            a.eval_rows[lrow] = (unsigned)std::min<unsigned long long>(0xffffu, ev.probe_wait >> 8) |
+                                ((unsigned)std::min<unsigned long long>(0xffffu, (__builtin_amdgcn_s_memtime() - t_row0) >> 8) << 16);
         ev.probe_acc[5] += __builtin_amdgcn_s_memtime() - t_row0;
         ev.probe_acc[6] += ev.probe_wait;
 #endif
         rowno++;
-        t = t_next;
+        t = t_next; nnz = nnz_next; p0 = p0_next; lrow = lrow_next;
     }
 #ifdef PMF_PROBE
     // kernel-wide sums of the first members' wave 0
