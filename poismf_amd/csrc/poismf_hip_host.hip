@@ -1303,6 +1303,7 @@ int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* 
         if (!rc && (hipStreamSynchronize(s->stream) != hipSuccess ||
                     hipMemcpy(A, s->dA, dimA * ks * sizeof(real_t), hipMemcpyDeviceToHost) != hipSuccess))
             rc = 1;
+        if (!rc) rc = team_check(s);
     }
     poismf_hip_session_destroy(s);
     if (rc) fprintf(stderr, "Error: out of memory.\n");
