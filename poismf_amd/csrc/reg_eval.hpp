@@ -225,7 +225,10 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     int pq_cap;
     T* pbuf;
     T* qbuf;
-    static constexpr bool CACHED = sizeof(T) == 8 && (NW_ == 1 || M_ > 1);   // compile-time: no trace of the cache in the other instances
+#ifndef PMF_CACHE32
+#define PMF_CACHE32 1
+#endif
+    static constexpr bool CACHED = (sizeof(T) == 8 && (NW_ == 1 || M_ > 1)) || (PMF_CACHE32 && sizeof(T) == 4);   // compile-time: no trace of the cache in the other instances
     static constexpr bool MAY_CACHE = CACHED;
     static constexpr bool CACHED_GRAD = CACHED;   // cg_row_cached may take gradients from the cached predictions
     T pv[CACHED ? NB : 1], qv[CACHED ? NB : 1];
