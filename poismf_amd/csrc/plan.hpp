@@ -98,7 +98,9 @@ unsigned reg_nnz_max(int method) { return method == POISMF_PG ? REG_NNZ_MAX : me
 
 constexpr int REG_NW_MAX = 8;   // the same engine with 2, 4 or 8 wavefronts per row
 // Several waves per row: the longest share of a row one wave keeps in registers, per solver (CG / TNCG carry more state)
-constexpr int REGW_WAVE_NNZ_MAX_PG = 160, REGW_WAVE_NNZ_MAX_CG = 128, REGW_WAVE_NNZ_MAX_TNCG = 96;
+// (CG: 144 although the 32- and 36-step fp32 instances spill 200-300 bytes per lane at two waves per SIMD -- for rows of
+// 1025-1152 nonzeros the alternative is the streamed LDS path: C4's matrix, CG fp32, B half 25.0 -> 16.8 ms)
+constexpr int REGW_WAVE_NNZ_MAX_PG = 160, REGW_WAVE_NNZ_MAX_CG = 144, REGW_WAVE_NNZ_MAX_TNCG = 96;
 unsigned regw_wave_nnz_max(int method)
 {
     return (unsigned)(method == POISMF_PG ? REGW_WAVE_NNZ_MAX_PG : method == POISMF_CG ? REGW_WAVE_NNZ_MAX_CG : REGW_WAVE_NNZ_MAX_TNCG);

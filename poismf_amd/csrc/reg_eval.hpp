@@ -220,8 +220,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     unsigned xseq;                    // exchanges so far
     // Cached line search (solvers.hpp, cg_row_cached): the predictions p_j = F_j . x and q_j = F_j . d of the nonzero each
     // lane finishes stay in registers (pv / qv, one per batch); pbuf / qbuf are only tags that tell eval() which of the
-    // two a pass is to keep.  Used by the fp64 single-wave kernels (pq_cap > 0): one wave per SIMD, where an Armijo trial
-    // as two logs instead of a pass over the tile is what shortens the row (C3 CG fp64 A half: 37.3 -> see DESIGN.md).
+    // two a pass is to keep.  First used by the fp64 single-wave kernels (pq_cap > 0): one wave per SIMD, where an Armijo trial
+    // as two logs instead of a pass over the tile is what shortens the row (C3 CG fp64 A half: 37.3 -> see DESIGN.md); the
+    // teams and, since the cache became a compile-time property of an instance, the fp32 kernels take it too (PMF_CACHE32).
     int pq_cap;
     T* pbuf;
     T* qbuf;

@@ -1,6 +1,6 @@
 """The register-tile engine (poismf_amd/csrc/reg_eval.hpp) at its edges, through the C-ABI, against the oracle:
 row lengths on either side of every hand-over (tile steps of 16 nonzeros; one wave -> two -> four -> eight waves per row
-at 160 / 320 / 640 for PG, 128 / 256 / 512 for CG, 96 / 192 / 384 for TNCG; -> the LDS engine at 1280 / 1024 / 768), the all-zero row that unused tile steps fetch, the padded gather copies, and
+at 160 / 320 / 640 for PG, 144 / 288 / 576 for CG, 96 / 192 / 384 for TNCG; -> the LDS engine at 1280 / 1152 / 768), the all-zero row that unused tile steps fetch, the padded gather copies, and
 agreement with the LDS engine on the same input (POISMF_HIP_NO_REGTILE=1 in a child process).  Needs an MI355X.
 
 Tolerances are those of tests/test_gpu_parity.py."""
@@ -41,9 +41,9 @@ def ragged_problem(lengths, dimB, k, use_float, seed):
     return csr, csc, A0, B0
 
 
-BOUNDARY_LENGTHS = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 162, 191, 192,
-                    193, 255, 256, 257, 319, 320, 321, 383, 384, 385, 511, 512, 513, 639, 640, 641, 767, 768, 769, 1023, 1024,
-                    1025, 1279, 1280, 1281, 1500]
+BOUNDARY_LENGTHS = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 143, 144, 145, 159, 160, 161, 162,
+                    191, 192, 193, 255, 256, 257, 287, 288, 289, 319, 320, 321, 383, 384, 385, 511, 512, 513, 575, 576, 577, 639, 640,
+                    641, 767, 768, 769, 1023, 1024, 1025, 1151, 1152, 1153, 1279, 1280, 1281, 1500]
 
 
 @pytest.mark.parametrize("method,k", [("pg", 50), ("cg", 50), ("tncg", 50), ("tncg", 13), ("pg", 7), ("cg", 13), ("pg", 64), ("pg", 1)])
