@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (GPU box): scripts/ab.sh <args for bench.py>   -- the same bench on the tree under _ab/old and on this tree, alternating, same box
+# (_ab/old: `git worktree add _ab/old <commit>` and `python -m poismf_amd.build` inside it, here, before the gpurun call; git-ignored)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for rep in 1 2; do
   for t in _ab/old .; do
