@@ -682,7 +682,9 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
         // s_nop wait states: A half 5.10 -> 5.81 ms -- the extra live registers cost more than the 59 s_nops per pass.
         // The matrix pipe as the adder: the four groups are the contraction index of a 16x16x4 MFMA's B operand, so
         // mfma(ones, part[i]) leaves the sum in every lane -- four MFMAs instead of eight bpermutes and eight adds, and 8-13
-        // fewer registers; but 32 issue cycles each: A half 5.09 -> 5.52 ms, B half 7.92 -> 8.52.)
+        // fewer registers; but 32 issue cycles each: A half 5.09 -> 5.52 ms, B half 7.92 -> 8.52.
+        // eval() phase by phase over the two batches of an eight-wave kernel (all dots, all butterflies, all coefficients, all
+        // axpys, so that one batch's DPP chains have the other's to interleave with): B half 7.85 -> 8.04 ms.)
         if constexpr (sizeof(T) == 8) {
 #pragma unroll
             for (int i = 0; i < NC; i++) part[i] = xor_sum<16>(part[i]);
