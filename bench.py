@@ -20,7 +20,8 @@ after each half the updated rows go to every peer over RCCL (poismf_amd/dist.py)
 Rank 0 prints ONE JSON line (see the driver contract); `roofline` prices the row-update kernels against HBM
 peak with SURVEY.md 8(d)'s algorithmic bytes, `cpu_baseline` is the compiled reference (oracle/_ref, kind
 "reference") timed on this box's host cores on the same matrix (steady state: the difference of a 2-iteration
-and a 1-iteration run).
+and a 1-iteration run).  `roofline.by_config` / `cpu_baseline.by_config` put the three lines of the metric side by side:
+PG with the reference's defaults (the headline), PG with hyper-parameters that keep the factors alive, CG fp64.
 """
 import argparse
 import json
@@ -119,6 +120,8 @@ class Job:
         dt = timed_sweeps(alt, steps, self.device)
         A, B = sess.get_factors()
         finite = bool(np.isfinite(A).all() and np.isfinite(B).all())
+        # "finite" only says no NaN / inf; a factor the solver has driven to all zeros is finite too -- report how much is alive
+        alive = {"A_nonzero_frac": float(np.count_nonzero(A)) / A.size, "B_nonzero_frac": float(np.count_nonzero(B)) / B.size}
         del A, B
         psteps = profile_steps or min(steps, 5)
         alt = fresh()
@@ -130,23 +133,28 @@ class Job:
         k_ms = [sess.kernel_time(w) for w in (0, 1)]
         ev_stats = [sess.eval_stats(w) for w in (0, 1)]
         plan = [sess.plan(w) for w in (0, 1)]
+        lprof = [sess.launch_profile(w) for w in (0, 1)]
         sess.profile(False)
-        return dict(method=method, maxupd=maxupd, l2=l2, step0=step0, steps=steps, seconds=dt, finite=finite, psteps=psteps,
-                    kernel_ms=k_ms, ev_stats=ev_stats, plan=plan)
+        return dict(method=method, maxupd=maxupd, l2=l2, step0=step0, steps=steps, seconds=dt, finite=finite, alive=alive, psteps=psteps,
+                    kernel_ms=k_ms, ev_stats=ev_stats, plan=plan, lprof=lprof)
 
     def close(self):
         self.be.close()
 
 
 def roofline_block(job, res, traffic_key=None):
-    """HBM roofline of the row-update kernels of one run, this rank's launches: algorithmic bytes of its two shards per
-    sweep / the summed duration of their launches per sweep."""
+    """HBM roofline of one run, this rank's launches.  `achieved` / `frac`: SURVEY.md 8(d)'s algorithmic bytes of the rank's two
+    shards per sweep / the UNPROFILED time of a sweep (the timed region: row kernels + column sums, profiling off).  The
+    row-kernel durations (`kernel_ms_*`, `frac_row_kernels`, `launches`) come from a separate profiled pass: HIP events on the
+    stream each launch is issued on, around every row-bin launch and around each half."""
     s = 4 if job.use_float else 8
     rA, rB = job.rangesA[job.rank], job.rangesB[job.rank]
     b_half = [algorithmic_bytes_half(job.nnz_local[0], rB[1] - rB[0], K, s), algorithmic_bytes_half(job.nnz_local[1], rA[1] - rA[0], K, s)]
     k_ms_half = [res["kernel_ms"][w][0] / res["psteps"] for w in (0, 1)]
     k_ms = sum(k_ms_half)
-    achieved = sum(b_half) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    sweep_ms = res["seconds"] / res["steps"] * 1e3
+    achieved = sum(b_half) / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    achieved_k = sum(b_half) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     rows = (rA[1] - rA[0]) + (rB[1] - rB[0])
     passes = res["ev_stats"][0][0] + res["ev_stats"][1][0]
     nnzp = res["ev_stats"][0][1] + res["ev_stats"][1][1]
@@ -158,18 +166,30 @@ def roofline_block(job, res, traffic_key=None):
             traffic = json.load(open(tf)).get(traffic_key)
         except Exception:
             traffic = None
-    # the launch with the most rows x tile steps names the dominant instance
-    launches = [(n, r) for w in (0, 1) for n, r in res["plan"][w]]
+    # per launch: algorithmic bytes of the rows it covers / its average duration
+    launches = []
+    for w in (0, 1):
+        for L in res["lprof"][w]:
+            by = L["nnz"] * (4 + s + K * s) + 2 * L["rows"] * K * s + L["rows"] * 8
+            ms = L["ms"] / max(L["calls"], 1)
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            launches.append({"kernel": L["kernel"], "half": "A" if w else "B", "rows": L["rows"], "nnz": L["nnz"], "avg_ms": ms,
+                             "calls": L["calls"], "algorithmic_bytes": int(by), "GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
+    dom = max(launches, key=lambda L: L["avg_ms"]) if launches else None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "row-update kernels of one sweep: " + "; ".join(f"{n} x{r} rows" for n, r in launches),
+            "sweep_ms_unprofiled": sweep_ms,
+            "dominant_kernel": dom,
+            "frac_row_kernels": achieved_k / HBM_PEAK_GBS,
             "kernel_ms_per_sweep": k_ms, "kernel_ms_B_half": k_ms_half[0], "kernel_ms_A_half": k_ms_half[1],
+            "launches": launches,
             "algorithmic_bytes_per_sweep": int(sum(b_half)), "half_sweeps_profiled": int(res["kernel_ms"][0][1] + res["kernel_ms"][1][1]),
             "pass_weighted": {"tile_passes_per_row": passes / res["psteps"] / max(rows, 1), "on_chip_GB_per_sweep": gb,
                               "on_chip_GBps": gb / (k_ms * 1e-3) if k_ms > 0 else 0.0},
-            "note": "achieved = algorithmic bytes of one sweep's row-kernel launches / their summed duration, measured in a separate "
-                    "profiled pass (HIP events on the session stream around each half's launches; launches are serial, so this equals "
-                    "sum(Calls x AverageNs) of the half_sweep_* rows of the rocprofv3 kernel stats under profiles/); bytes = "
-                    "nnz*(4+s+k*s) + 2*dimM*k*s + (dimM+1)*8 per half; traffic = fabric-side bytes per sweep from separate PMC passes"}
+            "note": "achieved / frac = algorithmic bytes of one sweep / the unprofiled wall time of one sweep (the timed region of this "
+                    "block); frac_row_kernels, kernel_ms_* and launches[] come from a separate profiled pass (HIP events on the stream "
+                    "each launch is issued on; launches are serial, so their sum equals sum(Calls x AverageNs) of the half_sweep_* rows "
+                    "of the rocprofv3 kernel stats under profiles/); dominant_kernel = the launch with the longest average duration; "
+                    "bytes = nnz*(4+s+k*s) + 2*dimM*k*s + (dimM+1)*8 per half; traffic = fabric-side bytes per sweep from separate PMC passes"}
 
 
 def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
@@ -191,9 +211,24 @@ def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
                     "ctypes, second call of the process (the first also pays device initialisation)"}
 
 
-def cpu_baseline(trip, method, use_float, maxupd):
+_CPU_CACHE = {}
+
+
+def _cpu_inputs(trip, use_float):
+    """host CSR / CSC (size_t indices) for the reference's ABI + the starting factors, once per precision"""
+    if use_float not in _CPU_CACHE:
+        _CPU_CACHE.clear()   # one precision at a time: 2.4-3.2 GB each
+        dimA, dimB = trip.shape
+        csr, csc = api.coo_to_csr_csc(trip, use_float)
+        _CPU_CACHE[use_float] = (csr, csc, harness.initialize_matrices(dimA, dimB, K, use_float, 1))
+    return _CPU_CACHE[use_float]
+
+
+def cpu_baseline(trip, method, use_float, maxupd, l2=None, step0=1e-7, iters=(1, 2)):
     """The compiled reference (oracle/_ref) on this box's host cores, same matrix: steady-state seconds per sweep =
-    t(2 outer iterations) - t(1 outer iteration).  Returns (cpu_baseline block, abi block)."""
+    (t(n2 outer iterations) - t(n1 outer iterations)) / (n2 - n1), after a small warm-up call that spins up the OpenMP team.
+    `value` is None when the difference is not positive (noise wins).  ref loops timed: src/poismf.c:506-608 with
+    pg_iteration :139-188 / cg_iteration :275-322 + src/nonnegcg.c:177-346."""
     from oracle import bindings
     try:
         import psutil
@@ -202,20 +237,27 @@ def cpu_baseline(trip, method, use_float, maxupd):
         cores = os.cpu_count()
     kind = "reference" if bindings.ref_available(use_float) else "port"
     lib = bindings.Reference(use_float) if kind == "reference" else bindings.Oracle(use_float)
-    l2, mu, _ = harness.auto_defaults(method, K)
+    l2d, mu, _ = harness.auto_defaults(method, K)
+    l2 = l2d if l2 is None else l2
     maxupd = mu if maxupd is None else maxupd
-    dimA, dimB = trip.shape
-    csr, csc = api.coo_to_csr_csc(trip, use_float)   # host CSR / CSC (size_t indices) for the reference's ABI
-    A0, B0 = harness.initialize_matrices(dimA, dimB, K, use_float, 1)
-    times = []
-    for iters in (1, 2):
+    csr, csc, (A0, B0) = _cpu_inputs(trip, use_float)
+
+    def run(n, rows=None):
         A, B = A0.copy(), B0.copy()
         t0 = time.perf_counter()
         with np.errstate(all="ignore"):
-            lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], l2, 0.0, 1.0, 1e-7, method, True, iters, maxupd,
+            lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], l2, 0.0, 1.0, step0, method, True, n, maxupd,
                            False, True, True, cores)
-        times.append(time.perf_counter() - t0)
-    dt = max(times[1] - times[0], 1e-9)
+        return time.perf_counter() - t0
+
+    if not _CPU_CACHE.get("warm"):
+        # warm-up: a 1-iteration PG(1) call creates the OpenMP threads and touches the matrix once
+        A, B = A0.copy(), B0.copy()
+        with np.errstate(all="ignore"):
+            lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], 1e9, 0.0, 1.0, 1e-7, "pg", True, 1, 1, False, True, True, cores)
+        _CPU_CACHE["warm"] = True
+    times = [run(n) for n in iters]
+    dt = (times[1] - times[0]) / (iters[1] - iters[0])
     nnz = len(csr[0])
     cpu = "unknown"
     try:
@@ -225,11 +267,11 @@ def cpu_baseline(trip, method, use_float, maxupd):
                 break
     except OSError:
         pass
-    abi = abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd)
-    return {"value": nnz / dt, "unit": "nnz/s per full sweep", "cores": int(cores), "kind": kind,
-            "sample": f"the whole workload matrix ({nnz} nnz), method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}: "
-                      f"run_poismf with 2 outer iterations ({times[1]:.2f} s) minus 1 outer iteration ({times[0]:.2f} s) = one steady-state "
-                      f"sweep, OpenMP threads={cores} on {cpu}"}, abi
+    return {"value": nnz / dt if dt > 0 else None, "unit": "nnz/s per full sweep", "cores": int(cores), "kind": kind,
+            "seconds_per_sweep": dt if dt > 0 else None,
+            "sample": f"the whole workload matrix ({nnz} nnz), method={method}, maxupd={maxupd}, l2={l2:g}, step={step0:g}, "
+                      f"{'fp32' if use_float else 'fp64'}: run_poismf with {iters[1]} outer iterations ({times[1]:.2f} s) minus {iters[0]} "
+                      f"({times[0]:.2f} s) = {iters[1] - iters[0]} steady-state sweep(s), after a warm-up call, OpenMP threads={cores} on {cpu}"}
 
 
 def main():
@@ -306,7 +348,7 @@ def main():
             r = j2.run(method, mu, st, 1, **kw)
             extra[name] = {"value": j2.nnz_local[1] * st / r["seconds"], "unit": "nnz/s", "ms_per_step": r["seconds"] / st * 1e3,
                            "dtype": "f32" if uf else "f64", "method": method, "maxupd": r["maxupd"], "l2": r["l2"], "step": r["step0"],
-                           "steps": st, "finite": r["finite"],
+                           "steps": st, "finite": r["finite"], "alive": r["alive"],
                            "roofline": roofline_block(j2, r, f"{a.workload}_{method}_maxupd{r['maxupd']}_{'f32' if uf else 'f64'}")}
     if rank == 0:
         sec = res["seconds"]
@@ -325,14 +367,41 @@ def main():
                        "setup_s": {"triplets": gen_s, "session_from_coo": headline_setup_s}},
             "roofline": headline_roofline,
             "results_finite": res["finite"],
+            "results_alive": dict(res["alive"], note="results_finite = no NaN / inf anywhere; it does NOT mean the factors are alive: with the "
+                                  "reference's Python defaults for pg (l2 1e9, step 1e-7) the reference's own arithmetic drives this matrix's "
+                                  "factors to exact zeros within the first sweeps (DESIGN.md 6.1) -- A/B_nonzero_frac say how much is left; the "
+                                  "by_config.pg_finite line times the same kernels on factors that stay positive"),
         }
         if extra:
             out["extra"] = extra
+        # the three lines of the metric side by side in the parsed line: PG with the reference's defaults (the headline), PG with
+        # hyper-parameters that keep the factors alive (same work per sweep), CG fp64 (config C3) -- each with its roofline numbers
+        head_name = f"{a.method}_maxupd{res['maxupd']}_{prec}_defaults"
+        byc = {head_name: {"value": out["value"], "ms_per_step": out["ms_per_step"], "frac": headline_roofline["frac"],
+                           "frac_row_kernels": headline_roofline["frac_row_kernels"], "dominant_kernel": headline_roofline["dominant_kernel"]}}
+        for name, blk in extra.items():
+            byc[name] = {"value": blk["value"], "ms_per_step": blk["ms_per_step"], "frac": blk["roofline"]["frac"],
+                         "frac_row_kernels": blk["roofline"]["frac_row_kernels"], "dominant_kernel": blk["roofline"]["dominant_kernel"]}
+        out["roofline"]["by_config"] = byc
         final_line = out
     if single and not a.no_cpu and rank == 0:
         job.close()
-        final_line["cpu_baseline"], abi = cpu_baseline(trip, a.method, use_float, a.maxupd)
-        final_line.setdefault("extra", {})["run_poismf_abi"] = abi
+        cb = cpu_baseline(trip, a.method, use_float, a.maxupd)
+        final_line["cpu_baseline"] = cb
+        csr, csc, _ = _cpu_inputs(trip, use_float)
+        final_line.setdefault("extra", {})["run_poismf_abi"] = abi_timing(csr, csc, dimA, dimB, a.method, use_float, a.maxupd)
+        del csr, csc
+        byc_cpu = {head_name: {k_: cb[k_] for k_ in ("value", "seconds_per_sweep", "cores", "kind")}}
+        if not a.no_extra:
+            # the other two lines of the metric get their CPU number too (fp32 inputs are still cached for the first)
+            for name, method, uf, kw in (("pg_maxupd10_f32_finite", "pg", True, dict(l2=1e3, step0=1e-9)), ("cg_f64", "cg", False, {})):
+                if name not in final_line.get("extra", {}):
+                    continue
+                c2 = cpu_baseline(trip, method, uf, None, **kw)
+                final_line["extra"][name]["cpu_baseline"] = c2
+                byc_cpu[name] = {k_: c2[k_] for k_ in ("value", "seconds_per_sweep", "cores", "kind")}
+        final_line["cpu_baseline"]["by_config"] = byc_cpu
+        _CPU_CACHE.clear()
     else:
         job.close()
     if dist.is_initialized():

@@ -255,6 +255,12 @@ POISMF_HIP_API int poismf_hip_session_topn(poismf_hip_session *s, size_t user,
  * per launch), NUL-terminated and truncated to cap bytes; returns the untruncated length.  Reporting only. */
 POISMF_HIP_API size_t poismf_hip_session_plan(poismf_hip_session *s, int which, char *buf, size_t cap);
 
+/* Profiling sessions (poismf_hip_session_profile(s, 1)) also bracket every row-bin launch with events on the stream it
+ * is issued on.  This returns, for half `which`, "kernel<instance> rows=R nnz=Z calls=C ms=T;" per distinct launch since
+ * profiling was switched on (T = summed milliseconds over the C calls; Z = nonzeros of the rows the launch covers, i.e.
+ * what its algorithmic bytes are computed from).  Same buffer convention as poismf_hip_session_plan.  Reporting only. */
+POISMF_HIP_API size_t poismf_hip_session_launch_profile(poismf_hip_session *s, int which, char *buf, size_t cap);
+
 /* Number of nonzeros held by this session for half `which` (shard only). */
 POISMF_HIP_API size_t poismf_hip_session_nnz(poismf_hip_session *s, int which);
 

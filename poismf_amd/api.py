@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_nnz", "poismf_hip_selftest_log", "poismf_hip_session_eval_stats",
     "poismf_hip_session_create_coo", "poismf_hip_session_stream", "poismf_hip_session_factors_dirty", "poismf_hip_session_run",
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
+    "poismf_hip_session_launch_profile",
     "poismf_hip_session_predict", "poismf_hip_session_topn",
 )
 
@@ -102,6 +103,8 @@ def load_library(use_float):
     lib.poismf_hip_session_topn.restype = i
     lib.poismf_hip_session_plan.argtypes = [vp, i, C.c_char_p, sz]
     lib.poismf_hip_session_plan.restype = sz
+    lib.poismf_hip_session_launch_profile.argtypes = [vp, i, C.c_char_p, sz]
+    lib.poismf_hip_session_launch_profile.restype = sz
     lib.poismf_hip_session_run.argtypes = [vp, C.POINTER(lib.params_t), sz, i]
     lib.poismf_hip_session_run.restype = i
     lib.poismf_hip_session_profile.argtypes = [vp, i]
@@ -503,13 +506,26 @@ class Session:
             raise MemoryError("poismf_hip_session_topn failed")
         return ix, sc
 
+    def _text(self, fn, which):
+        """a text report of the library, whole: ask for the length first (a fixed buffer cut long plans mid-item)"""
+        n = fn(self.h, int(which), None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        fn(self.h, int(which), buf, len(buf))
+        return [item.strip() for item in buf.value.decode().split(";") if item.strip()]
+
     def plan(self, which):
         """the launches of the most recent half-sweep of half `which`: [(kernel instance, rows), ...]"""
-        buf = C.create_string_buffer(8192)
-        self.lib.poismf_hip_session_plan(self.h, int(which), buf, len(buf))
         out = []
-        for item in buf.value.decode().split(";"):
-            if item.strip():
-                name, rows = item.rsplit(" rows=", 1)
-                out.append((name.strip(), int(rows)))
+        for item in self._text(self.lib.poismf_hip_session_plan, which):
+            name, rows = item.rsplit(" rows=", 1)
+            out.append((name.strip(), int(rows)))
+        return out
+
+    def launch_profile(self, which):
+        """per-launch timings of half `which` since profile(True): [dict(kernel, rows, nnz, calls, ms)], ms summed over calls"""
+        out = []
+        for item in self._text(self.lib.poismf_hip_session_launch_profile, which):
+            name, rest = item.split(" rows=", 1)
+            f = dict(kv.split("=") for kv in ("rows=" + rest).split())
+            out.append(dict(kernel=name.strip(), rows=int(f["rows"]), nnz=int(f["nnz"]), calls=int(f["calls"]), ms=float(f["ms"])))
         return out

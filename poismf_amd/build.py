@@ -18,7 +18,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "poismf_hip.h")
-_ROW = ["poismf_hip.hip", "plan.hpp", "devmem.hpp", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "wave_ops.hpp"]
+_ROW = ["poismf_hip.hip", "plan.hpp", "devmem.hpp", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "lane_eval.hpp", "wave_ops.hpp"]
 _HOST = ["poismf_hip_host.hip", "plan.hpp", "devmem.hpp", "row_eval.hpp", "wave_ops.hpp"]
 # unit -> (source files, first is the one compiled; extra flags).  poismf_hip.hip is compiled three times: one
 # translation unit per inner solver (its row kernels are the bulk of the compile time); the host side is its own file.

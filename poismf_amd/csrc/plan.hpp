@@ -151,6 +151,28 @@ inline TeamShape team_shape_for(unsigned max_nnz)
     return { 0, 0 };
 }
 
+// Lane-per-nonzero engine (lane_eval.hpp): doubles with 25 or 50 slots per factor row (k = 49..50, 99..100), CG and TNCG.
+// Lane sets (64 nonzeros each) per wave and waves per row for rows of a length class; sets 0 = not a row of this engine.
+// A function of the class bound alone, so a row's arithmetic does not depend on its shard.
+struct LaneShape { int sets, waves; };
+inline LaneShape lane_shape_for(unsigned cls, int s_load)
+{
+    if (sizeof(real_t) != 8) return { 0, 0 };
+    // (what the 512 registers of a wave hold next to the solver: two sets of a 25-slot tile -- 200 registers --, one of a
+    // 50-slot tile; four sets compile to > 1 KB of scratch per lane)
+    if (s_load == 25) {
+        if (cls <= 64) return { 1, 1 };
+        if (cls <= 128) return { 2, 1 };
+        if (cls <= 256) return { 2, 2 };
+        if (cls <= 512) return { 2, 4 };
+    } else if (s_load == 50) {
+        if (cls <= 64) return { 1, 1 };
+        if (cls <= 128) return { 1, 2 };
+        if (cls <= 256) return { 1, 4 };
+    }
+    return { 0, 0 };
+}
+
 // Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
 constexpr unsigned LONG_ROW_NNZ = 8192;
 constexpr int LONG_NW = 8;
@@ -169,6 +191,7 @@ int slots_per_lane(size_t k)
 struct OneLaunch {
     int reg_S, nw, s_load, spl;   // register-engine steps (0: LDS engine), waves per row, slots per factor row, slots per lane
     int team;                     // > 1: CUs per row (team launch)
+    int lane_L;                   // > 0: lane-per-nonzero engine with this many lane sets per wave (nw waves per row)
     bool generic_only;
     hipStream_t main_stream, bin_stream, long_stream;
     size_t lds;

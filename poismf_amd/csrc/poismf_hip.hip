@@ -14,6 +14,7 @@
 
 #include "plan.hpp"
 #include "reg_eval.hpp"
+#include "lane_eval.hpp"
 #include "solvers.hpp"
 
 // Translation units.  The row kernels of the three solvers are the bulk of the compile time, so the build compiles this
@@ -419,6 +420,17 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
 #endif
 }
 
+// Lane-per-nonzero engine (lane_eval.hpp): doubles, 25 or 50 slots per factor row; one wave per SIMD (the tile of two lane
+// sets is 200 architectural registers), NW waves per row.
+template <class T, int METHOD, int KS, int L, int NW>
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
+{
+    using EV = LaneEval<T, KS, L, NW>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
+    EV ev;
+    sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
+}
+
 namespace {
 
 constexpr int MAX_DEVICES = 64;        // per-device caches of kernel attributes below
@@ -519,6 +531,35 @@ template <int M, int S> int launch_team(hipStream_t stream, int method, const Ha
     } else return 1;
 }
 
+// lane-per-nonzero launches (doubles only)
+template <int METHOD, int KS, int L, int NW> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    if constexpr (sizeof(real_t) == 8 && tu_has(METHOD) && METHOD != K_PG) {
+        using EV = LaneEval<real_t, KS, L, NW>;
+        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, L, NW>;
+        // workgroups per CU: one wave per SIMD, and the LDS each takes
+        const int occ = std::max(1, std::min(4 / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
+        const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)t_num_cu * (size_t)occ * grid_mult);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    } else return 1;
+}
+template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int L, int nw, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    if (s_load == 25) {
+        if (L == 1 && nw == 1) return launch_lane<METHOD, 25, 1, 1>(stream, a, grid_mult);
+        if (L == 2 && nw == 1) return launch_lane<METHOD, 25, 2, 1>(stream, a, grid_mult);
+        if (L == 2 && nw == 2) return launch_lane<METHOD, 25, 2, 2>(stream, a, grid_mult);
+        if (L == 2 && nw == 4) return launch_lane<METHOD, 25, 2, 4>(stream, a, grid_mult);
+    } else if (s_load == 50) {
+        if (L == 1 && nw == 1) return launch_lane<METHOD, 50, 1, 1>(stream, a, grid_mult);
+        if (L == 1 && nw == 2) return launch_lane<METHOD, 50, 1, 2>(stream, a, grid_mult);
+        if (L == 1 && nw == 4) return launch_lane<METHOD, 50, 1, 4>(stream, a, grid_mult);
+    }
+    return 1;
+}
+
 template <int S, int NS, int NW> int launch_regw_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (S * REG_JG < 32) return 1;
@@ -573,6 +614,11 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
 {
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
+    if (o.lane_L > 0) {
+        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.nw, a, o.grid_mult);
+        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.nw, a, o.grid_mult);
+        return 1;
+    }
     if (o.team > 1) {
         if (o.team == 2 && o.reg_S == 32) return launch_team<2, 32>(o.main_stream, method, a);
         if constexpr (PMF_TEAM_S36) { if (o.team == 2 && o.reg_S == 36) return launch_team<2, 36>(o.main_stream, method, a); }

@@ -181,6 +181,7 @@ struct Bin {
     unsigned begin, count;  // range of the nnz-sorted permutation
     unsigned max_nnz;       // longest row actually in the bin (sizes tiles)
     unsigned cls;           // upper bound of the bin's length class (decides the code path: a function of the row alone)
+    unsigned long long nnz; // nonzeros of the bin's rows (algorithmic bytes of a launch, bench.py's per-launch roofline)
 };
 
 struct Half {
@@ -200,6 +201,8 @@ struct Half {
 };
 
 struct ProfRec { hipEvent_t t0, t1; int which; };
+// profiling sessions also bracket every row-bin launch (on the stream it is issued on): bench.py's per-launch roofline
+struct LaunchRec { hipEvent_t t0, t1; int which; std::string name; unsigned rows; unsigned long long nnz; };
 
 }  // namespace
 
@@ -228,6 +231,7 @@ struct poismf_hip_session {
     int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
     bool profiling = false;
     std::vector<ProfRec> prof;
+    std::vector<LaunchRec> lprof;
     std::string last_plan[2];         // the launches of the most recent half-sweep of each half, as text
 };
 
@@ -301,8 +305,9 @@ int finish_half(Half& h, hipStream_t stream, int nseg = 1)
     for (auto& sg : h.segs) {
         for (size_t i = sg.row_lo; i < sg.row_hi; i++) {
             const unsigned cls = length_class(len[i]);
-            if (sg.bins.empty() || cls != sg.bins.back().cls) sg.bins.push_back({ (unsigned)i, 0u, len[i], cls });   // sorted: the first row of a bin is its longest
+            if (sg.bins.empty() || cls != sg.bins.back().cls) sg.bins.push_back({ (unsigned)i, 0u, len[i], cls, 0ull });   // sorted: the first row of a bin is its longest
             sg.bins.back().count++;
+            sg.bins.back().nnz += len[i];
         }
     }
     return 0;
@@ -617,6 +622,8 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     if (s->aux_stream) (void)hipStreamSynchronize(s->aux_stream);
     for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
     s->prof.clear();
+    for (auto& p : s->lprof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
+    s->lprof.clear();
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     const hipStream_t own = s->owns_stream ? s->stream : nullptr, aux = s->aux_stream;
@@ -711,6 +718,8 @@ void poismf_hip_session_profile(poismf_hip_session* s, int enable)
     (void)hipStreamSynchronize(s->stream);
     for (auto& p : s->prof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
     s->prof.clear();
+    for (auto& p : s->lprof) { (void)hipEventDestroy(p.t0); (void)hipEventDestroy(p.t1); }
+    s->lprof.clear();
     s->profiling = enable != 0;
     for (Half& h : s->half) {
         const size_t n = h.row_end - h.row_begin;
@@ -842,7 +851,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
     // solver) are merged into one launch.
-    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; };
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0; };
     std::vector<Launch> launches;
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots (32 for doubles, two slots per lane), and 24-bit row ids / 32-bit
@@ -859,6 +868,12 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const bool no_team = getenv("POISMF_HIP_NO_TEAM") != nullptr;  // testing knob
     static const bool static_rows_ = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;
     const bool team_ok = !no_team && !static_rows_ && reg_ok && reg_ns == 2 && REG_G == 16 && sizeof(real_t) == 8 && p->method == POISMF_CG;
+    // lane-per-nonzero engine (lane_eval.hpp): doubles with 25 / 50 slots per factor row, CG and TNCG; 24-bit row ids and
+    // row strides, 32-bit byte offsets into the factor (as the register engine)
+    static const bool no_lane = getenv("POISMF_HIP_NO_LANE") != nullptr;  // testing knob
+    const bool lane_ok = !no_lane && sizeof(real_t) == 8 && (p->method == POISMF_CG || p->method == POISMF_TNCG) &&
+                         dimF < ((size_t)1 << 24) && ldF * sizeof(real_t) < ((size_t)1 << 24) &&
+                         (dimF + 1) * ldF * sizeof(real_t) + 16 < ((size_t)1 << 32);
     static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
     if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
@@ -868,6 +883,19 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     for (const Bin& b : bins) {
         TileGeom g = plan_geom(s->k, b.cls, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
+        if (lane_ok) {
+            const LaneShape ls = lane_shape_for(b.cls, g.s_load);
+            if (ls.sets > 0) {
+                if (!launches.empty() && launches.back().lane_L == ls.sets && launches.back().nw == ls.waves &&
+                    launches.back().begin + launches.back().count == b.begin)
+                    { launches.back().count += b.count; launches.back().nnz += b.nnz; }
+                else {
+                    launches.push_back({ b.begin, b.count, g, ls.waves, 0, 0, b.nnz });
+                    launches.back().lane_L = ls.sets;
+                }
+                continue;
+            }
+        }
         if (reg_ok && b.cls <= reg_max) {
             // short rows: the tile lives in registers (reg_eval.hpp); bins sharing a step count share a launch
             // (a bin of a few thousand rows is not worth a launch of its own: it rides along with the next longer size)
@@ -876,11 +904,11 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             // which other rows share its shard; PG and CG are bit-identical across instances and may ride along)
             const bool ride = p->method != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
             const int S = reg_steps_for(ride ? b.max_nnz : b.cls);
-            if (!launches.empty() && launches.back().nw == 1 && launches.back().reg_S >= S &&
+            if (!launches.empty() && launches.back().lane_L == 0 && launches.back().nw == 1 && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || (ride && b.count < 4096u)) && launches.back().begin + launches.back().count == b.begin)
-                launches.back().count += b.count;
+                { launches.back().count += b.count; launches.back().nnz += b.nnz; }
             else
-                launches.push_back({ b.begin, b.count, g, 1, S, 0 });
+                launches.push_back({ b.begin, b.count, g, 1, S, 0, b.nnz });
             continue;
         }
         if (regw_ok && b.cls <= regw_nnz_max(p->method)) {
@@ -888,22 +916,23 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             const int nw = regw_waves_for(b.cls, p->method);
             const bool ride = p->method != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
             const int S = regw_steps_for(ride ? b.max_nnz : b.cls, nw);
-            if (!launches.empty() && launches.back().nw == nw && launches.back().reg_S >= S &&
+            if (!launches.empty() && launches.back().lane_L == 0 && launches.back().nw == nw && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || (ride && b.count < 2048u)) && launches.back().begin + launches.back().count == b.begin)
-                launches.back().count += b.count;
+                { launches.back().count += b.count; launches.back().nnz += b.nnz; }
             else
-                launches.push_back({ b.begin, b.count, g, nw, S, 0 });
+                launches.push_back({ b.begin, b.count, g, nw, S, 0, b.nnz });
             continue;
         }
         if (team_ok) {
             // rows whose tile fits the registers of two to four CUs, not of one: a team per row (reg_eval.hpp, M_ > 1)
-            const TeamShape ts = team_shape_for(b.max_nnz);
+            const TeamShape ts = team_shape_for(b.cls);   // by the class bound, never by the longest row that happens to be in the bin: a row's
+            // share of the tile (my_share: C = ceil(nnz / (NW M))) -- and with it its summation order -- must not depend on its shard
             if (ts.members > 0) {
                 if (!launches.empty() && launches.back().team == ts.members && launches.back().reg_S == ts.steps &&
                     launches.back().begin + launches.back().count == b.begin)
-                    launches.back().count += b.count;
+                    { launches.back().count += b.count; launches.back().nnz += b.nnz; }
                 else
-                    launches.push_back({ b.begin, b.count, g, TEAM_NW, ts.steps, ts.members });
+                    launches.push_back({ b.begin, b.count, g, TEAM_NW, ts.steps, ts.members, b.nnz });
                 continue;
             }
         }
@@ -919,18 +948,18 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 if (cap <= 16 || lds_bytes_per_block(g, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
                 cap -= 16;
             }
-            if (!launches.empty() && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
-                launches.back().count += b.count;
+            if (!launches.empty() && launches.back().lane_L == 0 && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
+                { launches.back().count += b.count; launches.back().nnz += b.nnz; }
             else
-                launches.push_back({ b.begin, b.count, g, LONG_NW, 0, 0 });
+                launches.push_back({ b.begin, b.count, g, LONG_NW, 0, 0, b.nnz });
             continue;
         }
-        if (!launches.empty() && launches.back().reg_S == 0 && launches.back().geom.cap == g.cap &&
+        if (!launches.empty() && launches.back().lane_L == 0 && launches.back().reg_S == 0 && launches.back().geom.cap == g.cap &&
             launches.back().geom.resident == g.resident && (g.resident == 0) && g.pq_cap == 0 && launches.back().geom.pq_cap == 0 && launches.back().nw == 1 &&
             launches.back().begin + launches.back().count == b.begin)
-            launches.back().count += b.count;
+            { launches.back().count += b.count; launches.back().nnz += b.nnz; }
         else
-            launches.push_back({ b.begin, b.count, g, 1, 0, 0 });
+            launches.push_back({ b.begin, b.count, g, 1, 0, 0, b.nnz });
     }
     static const bool static_rows = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;  // testing knob
     const bool dynamic = !is_pg && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
@@ -943,7 +972,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const bool no_fork = getenv("POISMF_HIP_NO_FORK") != nullptr;  // testing knob
     static const bool fork_bins = getenv("POISMF_HIP_FORK_BINS") != nullptr;  // tuning knob
     bool any_long = false;
-    for (const Launch& L : launches) any_long = any_long || (L.nw > 1 && L.reg_S == 0);
+    for (const Launch& L : launches) any_long = any_long || (L.nw > 1 && L.reg_S == 0 && L.lane_L == 0);
     const bool forked = !no_fork && launches.size() > 1 && (any_long || fork_bins);
     hipStream_t long_stream = forked ? s->aux_stream : s->stream;
     double queued[2] = { 0.0, 0.0 };
@@ -954,15 +983,19 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     int launch_no = 0;
     if (prologue) s->last_plan[which].clear();
     for (const Launch& L : launches) {
+        char lname[160];
         {
             char txt[192];
             const char* m = is_pg ? "pg" : p->method == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
-            if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
+            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,L=%d,NW=%d> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.nw, L.count);
+            else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
             else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
             else if (L.reg_S > 0) snprintf(txt, sizeof txt, "half_sweep_regw_kernel<%s,%s,S=%d,NW=%d> rows=%u;", t, m, L.reg_S, L.nw, L.count);
             else snprintf(txt, sizeof txt, "half_sweep_kernel<%s,%s,NW=%d,%s cap=%d> rows=%u;", t, m, L.nw, L.geom.resident ? "resident" : "streamed", L.geom.cap, L.count);
             s->last_plan[which] += txt;
+            snprintf(lname, sizeof lname, "%s", txt);
+            if (char* sp = strstr(lname, " rows=")) *sp = 0;
         }
         a.queue = dynamic ? s->d_queue + launch_no : nullptr;
         launch_no++;
@@ -978,7 +1011,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         // waves let the dispatcher even that out (measured on C2, PG(10): 2 -> 1.214 ms, 8 -> 1.165, 32 -> 1.146).
         // The single-wave register kernels are always dealt out this way: with ~1 row per wave the hardware dispatcher IS
         // the queue (CG fp32 on C2: 3.87 ms with tickets, 3.35 ms without).
-        const bool one_wave_reg = L.reg_S > 0 && L.nw == 1;
+        const bool one_wave_reg = (L.reg_S > 0 || L.lane_L > 0) && L.nw == 1;
         if (one_wave_reg) a.queue = nullptr;
         a.team_buf = nullptr; a.team_err = s->d_team_err;
         if (L.team > 1) {
@@ -1000,13 +1033,26 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
             OneLaunch o;
-            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
+            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
             static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
             o.generic_only = generic_only;
             o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
             o.lds = lds; o.grid = grid; o.grid_mult = grid_mult;
             o.device = s->device; o.num_cu = s->num_cu;
+            // profiling sessions: events around this launch, on the stream it goes to (launch_one_here's choice)
+            hipStream_t lst = L.team > 1 || ((L.reg_S > 0 || L.lane_L > 0) && L.nw > 1) ? o.main_stream : (L.reg_S == 0 && L.lane_L == 0 && L.nw > 1 ? o.long_stream : o.bin_stream);
+            LaunchRec lr{};
+            if (s->profiling) {
+                HIP_TRY(hipEventCreate(&lr.t0));
+                HIP_TRY(hipEventCreate(&lr.t1));
+                lr.which = which; lr.name = lname; lr.rows = L.count; lr.nnz = L.nnz;
+                HIP_TRY(hipEventRecord(lr.t0, lst));
+            }
             rc = launch_one(p->method, o, a);
+            if (s->profiling) {
+                HIP_TRY(hipEventRecord(lr.t1, lst));
+                s->lprof.push_back(lr);
+            }
         }
         if (rc) return 1;
     }
@@ -1037,6 +1083,38 @@ int poismf_hip_half_sweep(poismf_hip_session* s, int which, const poismf_hip_par
 size_t poismf_hip_session_plan(poismf_hip_session* s, int which, char* buf, size_t cap)
 {
     const std::string& t = s->last_plan[which ? 1 : 0];
+    if (cap > 0) {
+        const size_t n = std::min(cap - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return t.size();
+}
+
+// Per-launch durations of half `which` since profile(1), launches of the same instance and row count added up:
+// "kernel<instance> rows=R nnz=Z calls=C ms=T;" per distinct launch (T = summed milliseconds).  NUL-terminated, truncated to
+// cap bytes; returns the untruncated length.
+size_t poismf_hip_session_launch_profile(poismf_hip_session* s, int which, char* buf, size_t cap)
+{
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamSynchronize(s->aux_stream);
+    struct Agg { std::string name; unsigned rows; unsigned long long nnz; unsigned calls; double ms; };
+    std::vector<Agg> agg;
+    for (auto& r : s->lprof) {
+        if (r.which != (which ? 1 : 0)) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.t0, r.t1) != hipSuccess) continue;
+        bool found = false;
+        for (auto& g : agg)
+            if (g.name == r.name && g.rows == r.rows && g.nnz == r.nnz) { g.calls++; g.ms += ms; found = true; break; }
+        if (!found) agg.push_back({ r.name, r.rows, r.nnz, 1u, (double)ms });
+    }
+    std::string t;
+    for (auto& g : agg) {
+        char txt[256];
+        snprintf(txt, sizeof txt, "%s rows=%u nnz=%llu calls=%u ms=%.6f;", g.name.c_str(), g.rows, g.nnz, g.calls, g.ms);
+        t += txt;
+    }
     if (cap > 0) {
         const size_t n = std::min(cap - 1, t.size());
         memcpy(buf, t.data(), n);
