@@ -3,9 +3,14 @@
 // Same contract as RegEval / RowEval: the factor rows F[ind_j] named by a row's nonzeros are fetched once and every inner
 // pass of the solver runs on chip.  The layout is the transpose of reg_eval.hpp's:
 //
-//   tile     t[s][c], s < L "lane sets", c < KP = 2 KS: lane l of set s holds ALL KP elements of F[ind_j], j = 64 s + l
+//   tile     t[s][c], s < LT "lane sets", c < KP = 2 KS: lane l of set s holds ALL KP elements of F[ind_j], j = 64 s + l
 //            (k = 50: 100 registers per set).  Nothing is padded to a power of two: 25 slots cost 25 slots (the slot
-//            layout of reg_eval.hpp pays for 32), and the tile sits in architectural registers, never in AGPRs.
+//            layout of reg_eval.hpp pays for 32).  Where a set lives is stated, not left to the register allocator (which,
+//            given two sets and the solver, parks half the tile in AGPRs and copies every element out for every use --
+//            measured: 43 % of the instructions of a pass): LV sets in architectural registers, LA sets in accumulator
+//            registers through explicit v_accvgpr_write / read (two reads per element and pass: for rows that outgrow
+//            everything else), LL sets in LDS -- the staged image of the gather simply stays where the DMA put it and is read
+//            with one conflict-free ds_read_b128 per slot (half an instruction per element and pass).
 //   k-vector lane <-> dimension, ONE copy per wave (NC = 1 element per lane for k <= 52, 2 for k <= 104): the solver's whole
 //            state is 2 NC registers per vector instead of 8, every element-wise statement of the solvers is one
 //            instruction, and nothing is computed four times over (the slot layout keeps four copies per wave).
@@ -61,16 +66,46 @@ template <int W> __device__ __forceinline__ double swap_fold(double a, double b)
     return __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0) + __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
 }
 
-template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
+// Nothing moves across this line: neither loads at the IR / instruction-selection level (the memory clobber; a bare
+// sched_barrier is no obstacle there, and hipcc then requests a whole pass's LDS reads at once and parks their 200 destination
+// registers -- in practice: the tile -- in AGPRs) nor anything in the machine scheduler.
+__device__ __forceinline__ void pin_here()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// AGPR-class values: written and read only through these (the "a" constraint makes the allocator keep them in the
+// accumulator half of the register file; nothing else of the kernel lives there)
+__device__ __forceinline__ unsigned acc_put(unsigned v)
+{
+    unsigned a;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+    return a;
+}
+__device__ __forceinline__ unsigned acc_get(unsigned a)
+{
+    unsigned v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+
+// SMALL_: one staging buffer, shared with the transpose scratch (14 KB of LDS per wave: eight waves per CU, two per SIMD, for
+// kernels whose registers allow that -- one set in architectural registers, nothing in AGPRs)
+template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false> struct LaneEval {
     static_assert(sizeof(T) == 8, "the lane-per-nonzero engine is instantiated for doubles");
     using SA = typename Slot<T>::A;
     static constexpr int SN = Slot<T>::N;                 // elements per 16-byte slot
     static constexpr int KP = KS * SN;                    // elements of a factor row, padded to whole slots
-    static constexpr int NC = (KP + WAVE - 1) / WAVE;     // elements of a k-vector per lane (dimension = lane + 64 i)
-    static constexpr int L = L_, NW = NW_, M = 1, NBUF = NBUF_;
-    static constexpr int W = KS < 13 ? KS : 13;           // slots per staged chunk (row stride of the LDS image: 13 slots = 52 banks, odd multiple of 4)
+    static constexpr int NC = (KP + WAVE - 1) / WAVE;     // elements of a k-vector per lane
+    static constexpr int LV = LV_, LA = LA_, LL = LL_, LR = LV_ + LA_, LT = LV_ + LA_ + LL_;   // sets: VGPR, AGPR, LDS
+    static constexpr int L = LT, NW = NW_, M = 1;
+    static constexpr int W = KS < 13 ? KS : 13;           // slots per staged chunk (row stride of the LDS image: 13 slots = 52 banks, conflict-free b128 reads)
     static constexpr int NCH = (KS + W - 1) / W;          // chunks per factor row; chunk c starts at slot min(c W, KS - W)
     static constexpr int STAGE_BYTES = WAVE * W * 16;
+    static constexpr int NBUF = LL_ > 0 ? LL_ * NCH : (SMALL_ ? 1 : 2);  // staging buffers; the chunks of the LDS sets stay in theirs
+    static constexpr bool ALIAS = SMALL_;
+    static_assert(!SMALL_ || LL_ == 0, "the shared buffer is free once the gather is done");
     static_assert(KP % NC == 0, "blocks of equal size");
     static constexpr int DB = KP / NC;                    // dimensions per 64-lane block
     static constexpr int CW = (DB + 3) / 4;               // columns: dimension d' of a block lives in lane (d' % CW) + 16 (d' / CW)
@@ -78,8 +113,6 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
     static constexpr int RED_STRIDE = 18 * 8;             // bytes between the 16-double rows of the transpose scratch (conflict-free b128 reads)
     static constexpr int RED_BYTES = 4 * 16 * RED_STRIDE; // four 16-lane rows x up to 16 columns
     static constexpr int AVEC_BYTES = (KP * 8 + 15) / 16 * 16;
-    // NBUF == 1: the transpose scratch shares the staging buffer (eight waves per CU: 20 KB of LDS each)
-    static constexpr bool ALIAS = NBUF_ == 1;
     static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + (ALIAS ? 0 : RED_BYTES) + AVEC_BYTES;
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
     static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * 8 + 16 * ((NW_ * 8 + 15) / 16) : 0;
@@ -89,11 +122,13 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
     static constexpr bool CACHED = true, MAY_CACHE = true, CACHED_GRAD = true;
     static constexpr int LS_BATCH = 1;
     static_assert(KS >= 13 && KP <= 2 * WAVE, "25 or 50 slots");
+    static_assert(LV_ >= 1, "at least one set in architectural registers");
 
-    T t[L][KP];          // the tile
-    T xr[L];             // x_j of this lane's nonzeros
-    unsigned idx_n[L];   // column indices of the row whose tile is requested next (fetch_meta -> gather)
-    T pv[L], qv[L];      // cached predictions p_j = F_j . x and q_j = F_j . d (solvers.hpp, cg_row_cached)
+    T t[LV][KP];                          // the sets in architectural registers
+    unsigned ta[LA > 0 ? LA : 1][KP][2];  // the sets in accumulator registers (AGPR-class values: acc_put / acc_get only)
+    T xr[LT];            // x_j of this lane's nonzeros
+    unsigned idx_n[LT];  // column indices of the row whose tile is requested next (fetch_meta -> gather)
+    T pv[LT], qv[LT];    // cached predictions p_j = F_j . x and q_j = F_j . d (solvers.hpp, cg_row_cached)
     const T* F;
     unsigned zero_row;
     int k, ldF;
@@ -145,6 +180,29 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
 
     // ---- k-vectors: lane <-> dimension -------------------------------------------------------------------------------
+    // Several wave-wide sums at once (the solvers' dot products come in groups: theta / beta / |g|^2; g.d / d.d; the three
+    // sums of a line-search trial): two swap-fold levels put sum i into the lanes of 16-lane row (i & 1) * 2 + (i >> 1) --
+    // three instructions per fold instead of one full reduction per value --, ONE 16-lane DPP reduction finishes all of
+    // them, and a v_readlane pair per value hands them out.  29 instructions for four sums, 22 for two; 25 each one by one.
+    static constexpr bool FUSED_SUMS = true;
+    template <int N> __device__ __forceinline__ void rsum_n(T (&v)[N]) const
+    {
+        static_assert(N >= 1 && N <= 4, "up to four sums per reduction");
+        T u;
+        if constexpr (N == 1) u = swap_fold<16>(swap_fold<32>(v[0], v[0]), swap_fold<32>(v[0], v[0]));
+        else if constexpr (N == 2) { const T w = swap_fold<32>(v[0], v[1]); u = swap_fold<16>(w, w); }
+        else if constexpr (N == 3) u = swap_fold<16>(swap_fold<32>(v[0], v[1]), swap_fold<32>(v[2], v[2]));
+        else u = swap_fold<16>(swap_fold<32>(v[0], v[1]), swap_fold<32>(v[2], v[3]));
+        u = u + dpp_mov<0xB1>(u);
+        u = u + dpp_mov<0x4E>(u);
+        u = u + dpp_mov<0x141>(u);
+        u = u + dpp_mov<0x140>(u);
+        // rows: 0 holds v[0]; N >= 3: 1 holds v[2]; 2 holds v[1]; 3 holds v[3]   (N == 2: rows 0, 1 hold v[0], rows 2, 3 v[1])
+        v[0] = uniform(u);
+        if constexpr (N >= 2) v[1] = read_lane(u, 32);
+        if constexpr (N >= 3) v[2] = read_lane(u, 16);
+        if constexpr (N >= 4) v[3] = read_lane(u, 48);
+    }
     template <class V> __device__ __forceinline__ V rsum(V x) const { return wave_sum(x); }
     template <class V> __device__ __forceinline__ V rmin(V x) const { return wave_min(x); }
     template <class V> __device__ __forceinline__ V rmax(V x) const { return wave_max(x); }
@@ -189,7 +247,7 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
         unsigned c0, mine;
         my_share(nnz_row, c0, mine);
 #pragma unroll
-        for (int s = 0; s < L; s++) {
+        for (int s = 0; s < LT; s++) {
             const unsigned j = (unsigned)(WAVE * s + lane);
             idx_n[s] = j < mine ? ind[c0 + j] : zero_row;   // lanes past the end of the row fetch the all-zero row behind F
         }
@@ -200,7 +258,11 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
         gather(val, nnz_row);
     }
 
-    // One chunk (slots [q0, q0 + W) of the 64 factor rows named by idx) -> staging buffer `buf`, as W LDS-DMA instructions.
+    static constexpr int chunk_start(int c) { return c * W < KS - W ? c * W : KS - W; }
+    static constexpr int chunk_lo(int c) { return c == 0 ? 0 : chunk_start(c - 1) + W; }   // first slot the chunk is the first to bring
+    static constexpr int slot_chunk(int q) { int c = 0; while (q >= chunk_start(c) + W) c++; return c; }   // the chunk slot q is read from
+
+    // One chunk (slots [Q0, Q0 + W) of the 64 factor rows named by idx) -> staging buffer `buf`, as W LDS-DMA instructions.
     // Slot sigma = 64 i + lane of the row-major image [row][W slots] is row sigma / W, slot sigma % W.
     template <int Q0> __device__ __forceinline__ void dma_chunk(unsigned idx, int buf)
     {
@@ -222,7 +284,7 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
             j4 = wrap ? j4 + 4u : j4;
         });
     }
-    // staged chunk -> this lane's slots [QLO, QHI) of set s (the chunk starts at slot Q0)
+    // staged chunk -> this lane's slots [QLO, QHI) of register set S_ (the chunk starts at slot Q0)
     template <int S_, int Q0, int QLO, int QHI> __device__ __forceinline__ void read_chunk(int buf)
     {
         const SA* src = (const SA*)(stage + buf * STAGE_BYTES) + lane * W;
@@ -230,51 +292,88 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
             constexpr int q = decltype(qc)::value;
             const SA v = src[q - Q0];
 #pragma unroll
-            for (int e = 0; e < SN; e++) t[S_][q * SN + e] = v.v[e];
+            for (int e = 0; e < SN; e++) {
+                if constexpr (S_ < LV) t[S_][q * SN + e] = v.v[e];
+                else {
+                    const unsigned long long b = __builtin_bit_cast(unsigned long long, v.v[e]);
+                    ta[S_ - LV][q * SN + e][0] = acc_put((unsigned)b);
+                    ta[S_ - LV][q * SN + e][1] = acc_put((unsigned)(b >> 32));
+                }
+            }
         });
     }
-    static constexpr int chunk_start(int c) { return c * W < KS - W ? c * W : KS - W; }
-    static constexpr int chunk_lo(int c) { return c == 0 ? 0 : chunk_start(c - 1) + W; }   // first slot the chunk is the first to bring
-    __device__ __forceinline__ void wait_dma(int outstanding)
+    template <int OUTSTANDING_CHUNKS> __device__ __forceinline__ void wait_dma()
     {
         // LDS-DMA data is ordered for this wave's ds_reads by its own vmcnt (MI355X_MICROARCH.md, two waves per SIMD, item 7)
-        if (outstanding == 0) __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(0x0f70 | (W & 0xf) | ((W >> 4) << 14));   // vmcnt(W): the older chunk has landed
+        constexpr int n = OUTSTANDING_CHUNKS * W;
+        if constexpr (n == 0) __builtin_amdgcn_s_waitcnt(0x0f70);                                          // vmcnt(0)
+        else if constexpr (n < 64) __builtin_amdgcn_s_waitcnt(0x0f70 | (n & 0xf) | ((n >> 4) << 14));      // vmcnt(n): the older chunks have landed
         wave_lds_fence();
     }
     __device__ __forceinline__ void gather(const T* val, unsigned nnz_row)
     {
         unsigned c0;
         my_share(nnz_row, c0, nnz);
-        unsigned idx[L];
+        unsigned idx[LT];
 #pragma unroll
-        for (int s = 0; s < L; s++) {
+        for (int s = 0; s < LT; s++) {
             const unsigned j = (unsigned)(WAVE * s + lane);
             idx[s] = idx_n[s];
             xr[s] = j < nnz ? val[c0 + j] : (T)0;
         }
-        // chunks in flight: NBUF.  Work list: (set, chunk) pairs in order.
-        constexpr int NWORK = L * NCH;
-        static_for<0, NWORK>([&](auto wc) {
+        // Sets in architectural registers: every lane loads its own factor row, 16 bytes at a time, straight into the tile --
+        // KS loads in flight per lane, no staging, no address arithmetic beyond the row's base.  (64 different rows per
+        // instruction: the price is in the texture unit -- 64 tag look-ups per instruction -- which a row pays once; the lines
+        // are the same 2-4 per row that a coalesced fetch would bring.)
+#ifndef PMF_LANE_DIRECT
+#define PMF_LANE_DIRECT 1
+#endif
+        constexpr int S0 = PMF_LANE_DIRECT ? LV : 0;   // first set that goes through the staging buffers
+        if constexpr (PMF_LANE_DIRECT) {
+            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+            static_for<0, LV>([&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                const char* base = (const char*)F + (size_t)__umul24(idx[s2], rowbytes);
+                static_for<0, KS>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const typename Slot<T>::U v = *(const typename Slot<T>::U*)(base + q * 16);
+#pragma unroll
+                    for (int e = 0; e < SN; e++) t[s2][q * SN + e] = v.v[e];
+                });
+            });
+        }
+        // the other register sets: their chunks pass through the staging buffers, NBUF in flight
+        constexpr int NWORK = (LR - S0) * NCH;
+        constexpr int DEPTH = NBUF < NWORK ? NBUF : NWORK;
+        static_for<0, DEPTH>([&](auto wc) {
             constexpr int w = decltype(wc)::value;
-            constexpr int s = w / NCH, c = w % NCH;
-            if constexpr (w < NBUF) dma_chunk<chunk_start(c)>(idx[s], w % NBUF);
+            dma_chunk<chunk_start(w % NCH)>(idx[S0 + w / NCH], w % NBUF);
         });
         static_for<0, NWORK>([&](auto wc) {
             constexpr int w = decltype(wc)::value;
-            constexpr int s = w / NCH, c = w % NCH;
-            constexpr int inflight_after = (NWORK - 1 - w) < (NBUF - 1) ? (NWORK - 1 - w) : (NBUF - 1);
-            wait_dma(inflight_after);
+            constexpr int s = S0 + w / NCH, c = w % NCH;
+            constexpr int later = NWORK - 1 - w;   // chunks requested after this one so far: min(later, DEPTH - 1)
+            wait_dma<(later < DEPTH - 1 ? later : DEPTH - 1)>();
             read_chunk<s, chunk_start(c), chunk_lo(c), chunk_start(c) + W>(w % NBUF);
-            if constexpr (w + NBUF < NWORK) {
-                constexpr int w2 = w + NBUF, s2 = w2 / NCH, c2 = w2 % NCH;
+            if constexpr (w + DEPTH < NWORK || LL > 0) {
                 // the reads of this buffer must have returned before the next DMA lands in it
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
                 wave_lds_fence();
-                dma_chunk<chunk_start(c2)>(idx[s2], w % NBUF);
+            }
+            if constexpr (w + DEPTH < NWORK) {
+                constexpr int w2 = w + DEPTH;
+                dma_chunk<chunk_start(w2 % NCH)>(idx[S0 + w2 / NCH], w % NBUF);
             }
         });
-        if constexpr (ALIAS) { __builtin_amdgcn_s_waitcnt(0xc07f); wave_lds_fence(); }
+        if constexpr (ALIAS) { __builtin_amdgcn_s_waitcnt(0xc07f); wave_lds_fence(); }   // the scratch of the reductions is this buffer
+        // LDS sets: their chunks stay in the buffers (set u, chunk c in buffer u NCH + c)
+        if constexpr (LL > 0) {
+            static_for<0, LL * NCH>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                dma_chunk<chunk_start(w % NCH)>(idx[LR + w / NCH], w);
+            });
+            wait_dma<0>();
+        }
     }
 
     __device__ __forceinline__ void set_point(const T (&x)[NC])
@@ -287,35 +386,96 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
         wave_lds_fence();
     }
 
-    // ---- the transposing reduction: KP lane-partials per lane -> the total of dimension lane + 64 b in this lane -----------
-    // val(c): this lane's partial of dimension c (c < KP)
-    template <int C> __device__ __forceinline__ T partial(const T (&coef)[L]) const
+    // ---- tile access -----------------------------------------------------------------------------------------------------
+    // slot Q (SN elements) of this lane's nonzero in set S
+    template <int S, int Q> __device__ __forceinline__ SA tile_slot() const
     {
-        T v = coef[0] * t[0][C];
+        SA v;
+        if constexpr (S < LV) {
 #pragma unroll
-        for (int s = 1; s < L; s++) v = fma_t(coef[s], t[s][C], v);
+            for (int e = 0; e < SN; e++) v.v[e] = t[S][Q * SN + e];
+        } else if constexpr (S < LR) {
+#pragma unroll
+            for (int e = 0; e < SN; e++) {
+                const unsigned lo = acc_get(ta[S - LV][Q * SN + e][0]), hi = acc_get(ta[S - LV][Q * SN + e][1]);
+                v.v[e] = __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+            }
+        } else {
+            constexpr int c = slot_chunk(Q);
+            v = *((const SA*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + lane * W + (Q - chunk_start(c)));
+        }
         return v;
     }
-    // the two dimensions col + CW R0 (kept by the lanes of the lower half-wave) and col + CW (R0 + 2) (upper) of block B
-    template <int B, int COL, int R0> __device__ __forceinline__ T level_a(const T (&coef)[L]) const
+    // element C of this lane's nonzero in set S
+    template <int S, int C> __device__ __forceinline__ T tile_elem() const
     {
-        constexpr int d0 = COL + CW * R0, d1 = COL + CW * (R0 + 2);
-        static_assert(d0 < DB, "a dimension of the block");
-        const T a = partial<DB * B + d0>(coef);
-        if constexpr (d1 < DB) return swap_fold<32>(a, partial<DB * B + d1>(coef));
+        if constexpr (S < LV) return t[S][C];
+        else if constexpr (S < LR) {
+            const unsigned lo = acc_get(ta[S - LV][C][0]), hi = acc_get(ta[S - LV][C][1]);
+            return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+        } else {
+            constexpr int q = C / SN, c = slot_chunk(q);
+            return *((const T*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + (lane * W + (q - chunk_start(c))) * SN + C % SN);
+        }
+    }
+
+    // ---- the transposing reduction: KP lane-partials per lane -> the total of each dimension in the lane that holds it -----
+    // The elements of the LDS sets that column COL needs (dimensions COL + CW r, r < 4, of block B), requested one column
+    // ahead of their use; sched_barriers keep the compiler from requesting the whole tile at once (left alone it puts all 50
+    // reads of a pass in flight and parks their 200 destination registers in AGPRs).
+    static constexpr int LLX = LL > 0 ? LL : 1;
+    template <int B, int COL> __device__ __forceinline__ void load_col(T (&tl)[4][LLX]) const
+    {
+        static_for<0, 4>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int d = COL + CW * r;
+            if constexpr (d < DB) {
+                static_for<0, LL>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    tl[r][u] = tile_elem<LR + u, DB * B + d>();
+                });
+            }
+        });
+    }
+    // this lane's partial of dimension DB B + COL + CW R
+    template <int B, int COL, int R> __device__ __forceinline__ T partial(const T (&coef)[LT], const T (&tl)[4][LLX]) const
+    {
+        constexpr int C = DB * B + COL + CW * R;
+        T v = coef[0] * t[0][C];
+        static_for<1, LR>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            v = fma_t(coef[s], tile_elem<s, C>(), v);
+        });
+        static_for<0, LL>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            v = fma_t(coef[LR + u], tl[R][u], v);
+        });
+        return v;
+    }
+    // the two dimensions COL + CW R0 (kept by the lanes of the lower half-wave) and COL + CW (R0 + 2) (upper) of block B
+    template <int B, int COL, int R0> __device__ __forceinline__ T level_a(const T (&coef)[LT], const T (&tl)[4][LLX]) const
+    {
+        static_assert(COL + CW * R0 < DB, "a dimension of the block");
+        const T a = partial<B, COL, R0>(coef, tl);
+        if constexpr (COL + CW * (R0 + 2) < DB) return swap_fold<32>(a, partial<B, COL, R0 + 2>(coef, tl));
         else return swap_fold<32>(a, a);   // (the upper half-wave's result belongs to no dimension)
     }
-    template <int B> __device__ __forceinline__ T reduce_block(const T (&coef)[L])
+    template <int B> __device__ __forceinline__ T reduce_block(const T (&coef)[LT])
     {
         const int R = lane >> 4, p = lane & 15;
         unsigned char* wr = red + R * (16 * RED_STRIDE) + p * 8;
+        T tl[2][4][LLX];
+        load_col<B, 0>(tl[0]);
         static_for<0, CW>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            const T x = level_a<B, c, 0>(coef);         // rows 0 | 2
+            if constexpr (c + 1 < CW) load_col<B, c + 1>(tl[(c + 1) & 1]);
+            pin_here();
+            const T x = level_a<B, c, 0>(coef, tl[c & 1]);         // rows 0 | 2
             T o;
-            if constexpr (c + CW < DB) o = swap_fold<16>(x, level_a<B, c, 1>(coef));   // rows 1 | 3
+            if constexpr (c + CW < DB) o = swap_fold<16>(x, level_a<B, c, 1>(coef, tl[c & 1]));   // rows 1 | 3
             else o = swap_fold<16>(x, x);
             *(T*)(wr + c * RED_STRIDE) = o;             // lane (R, p): dimension c + CW R, summed over the four lanes (., p)
+            pin_here();
         });
         wave_lds_fence();
         const SA* rd = (const SA*)(red + R * (16 * RED_STRIDE) + p * RED_STRIDE);
@@ -370,34 +530,65 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
     template <bool WANT_F, bool WANT_G, bool FROM_CACHE = false> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
     {
         n_eval++;
-        T pred[L];
+        T pred[LT];
         if constexpr (FROM_CACHE) {
 #pragma unroll
-            for (int s = 0; s < L; s++) pred[s] = pv[s];
+            for (int s = 0; s < LT; s++) pred[s] = pv[s];
         } else {
-            static_for<0, KS>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                const SA av = avec[q];                      // the same address in every lane: a broadcast read
+            // slots in groups of GQ: the point (a broadcast read) and the LDS sets' slots of the NEXT group are requested
+            // before the current group's multiply-adds
+            constexpr int GQ = 5, NG = (KS + GQ - 1) / GQ;
+            SA av[2][GQ], tl[2][LLX][GQ];
+            auto load_group = [&](auto gc, SA (&a_)[GQ], SA (&t_)[LLX][GQ]) {
+                constexpr int g = decltype(gc)::value;
+                static_for<0, GQ>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, q = g * GQ + i;
+                    if constexpr (q < KS) {
+                        a_[i] = avec[q];                    // the same address in every lane
+                        static_for<0, LL>([&](auto uc) {
+                            constexpr int u = decltype(uc)::value;
+                            t_[u][i] = tile_slot<LR + u, q>();
+                        });
+                    }
+                });
+            };
+            load_group(std::integral_constant<int, 0>{}, av[0], tl[0]);
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, av[(g + 1) & 1], tl[(g + 1) & 1]);
+                pin_here();
+                static_for<0, GQ>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, q = g * GQ + i;
+                    if constexpr (q < KS) {
+                        static_for<0, LT>([&](auto sc) {
+                            constexpr int s2 = decltype(sc)::value;
+                            SA tv;
+                            if constexpr (s2 < LR) tv = tile_slot<s2, q>();
+                            else tv = tl[g & 1][s2 - LR][i];
+                            if constexpr (q == 0) pred[s2] = tv.v[0] * av[g & 1][i].v[0];
+                            else pred[s2] = fma_t(tv.v[0], av[g & 1][i].v[0], pred[s2]);
 #pragma unroll
-                for (int s = 0; s < L; s++) {
-                    if constexpr (q == 0) pred[s] = t[s][0] * av.v[0];
-                    else pred[s] = fma_t(t[s][q * SN], av.v[0], pred[s]);
+                            for (int e = 1; e < SN; e++) pred[s2] = fma_t(tv.v[e], av[g & 1][i].v[e], pred[s2]);
+                        });
+                    }
+                });
+                // (the multiply-adds are no memory operations: what ties them to this side of the line is the value they produce)
 #pragma unroll
-                    for (int e = 1; e < SN; e++) pred[s] = fma_t(t[s][q * SN + e], av.v[e], pred[s]);
-                }
+                for (int s2 = 0; s2 < LT; s2++) asm volatile("" : "+v"(pred[s2]));
+                pin_here();
             });
         }
         if (store == pbuf) {
 #pragma unroll
-            for (int s = 0; s < L; s++) pv[s] = pred[s];
+            for (int s = 0; s < LT; s++) pv[s] = pred[s];
         } else if (store == qbuf) {
 #pragma unroll
-            for (int s = 0; s < L; s++) qv[s] = pred[s];
+            for (int s = 0; s < LT; s++) qv[s] = pred[s];
         }
         double lpart = 0.0;
-        T coef[L];
+        T coef[LT];
 #pragma unroll
-        for (int s = 0; s < L; s++) {
+        for (int s = 0; s < LT; s++) {
             const bool on = (unsigned)(WAVE * s + lane) < nnz;
             if constexpr (WANT_F) lpart += on ? (double)xr[s] * d_log((double)pred[s]) : 0.0;
             if constexpr (WANT_G) coef[s] = on ? coef_div(sgn * xr[s], pred[s]) : (T)0;
@@ -439,7 +630,7 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
         double lpart = 0.0;
         bool bad = false;
 #pragma unroll
-        for (int s = 0; s < L; s++) {
+        for (int s = 0; s < LT; s++) {
             const bool on = (unsigned)(WAVE * s + lane) < nnz;
             const T pred = fma_t(alpha, qv[s], pv[s]);
             bad = bad || (on && !(pred > pv[s] * (T)1e-4));
@@ -457,6 +648,31 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
         }
         return l;
     }
+    // the same, un-reduced: this lane's share of sum_j x_j log(p_j + alpha q_j), and whether any of its predictions cancelled
+    __device__ __forceinline__ double logsum_cached_lane(T alpha, bool& bad) const
+    {
+        double lpart = 0.0;
+        bad = false;
+#pragma unroll
+        for (int s = 0; s < LT; s++) {
+            const bool on = (unsigned)(WAVE * s + lane) < nnz;
+            const T pred = fma_t(alpha, qv[s], pv[s]);
+            bad = bad || (on && !(pred > pv[s] * (T)1e-4));
+            lpart += on ? (double)xr[s] * d_log((double)pred) : 0.0;
+        }
+        return lpart;
+    }
+    // NW > 1: a wave-uniform scalar summed over the row's waves (NaN in any wave poisons the sum: every wave takes the same branch)
+    __device__ __forceinline__ double combine_scalar(double l)
+    {
+        if constexpr (NW > 1) {
+            T none[NC];
+#pragma unroll
+            for (int i = 0; i < NC; i++) none[i] = (T)0;
+            combine_waves(none, l, false);
+        }
+        return l;
+    }
     __device__ __forceinline__ void logsum_cached_batch(T alpha, T, double (&ls)[LS_BATCH], bool (&trusted)[LS_BATCH])
     {
         ls[0] = logsum_cached(alpha, trusted[0]);
@@ -464,15 +680,15 @@ template <class T, int KS, int L_, int NW_ = 1, int NBUF_ = 2> struct LaneEval {
     __device__ __forceinline__ void advance_cached(T alpha)
     {
 #pragma unroll
-        for (int s = 0; s < L; s++) pv[s] = fma_t(alpha, qv[s], pv[s]);
+        for (int s = 0; s < LT; s++) pv[s] = fma_t(alpha, qv[s], pv[s]);
     }
 
     // acc_c += sum_j F[ind_j, c]  (adjustment_Bsum's gather pass, ref: src/poismf.c:108-110)
     __device__ __forceinline__ void tile_colsum(T (&acc)[NC])
     {
-        T one[L];
+        T one[LT];
 #pragma unroll
-        for (int s = 0; s < L; s++) one[s] = (T)1;   // lanes past the row's end hold the zero row
+        for (int s = 0; s < LT; s++) one[s] = (T)1;   // lanes past the row's end hold the zero row
         T tot[NC];
         static_for<0, NC>([&](auto bc) {
             constexpr int b = decltype(bc)::value;

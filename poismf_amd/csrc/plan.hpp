@@ -152,25 +152,28 @@ inline TeamShape team_shape_for(unsigned max_nnz)
 }
 
 // Lane-per-nonzero engine (lane_eval.hpp): doubles with 25 or 50 slots per factor row (k = 49..50, 99..100), CG and TNCG.
-// Lane sets (64 nonzeros each) per wave and waves per row for rows of a length class; sets 0 = not a row of this engine.
-// A function of the class bound alone, so a row's arithmetic does not depend on its shard.
-struct LaneShape { int sets, waves; };
+// Lane sets (64 nonzeros each) per wave -- in architectural registers, in accumulator registers, in LDS -- and waves per row
+// for rows of a length class; waves 0 = not a row of this engine.  A function of the class bound alone, so a row's
+// arithmetic does not depend on its shard.
+struct LaneShape { int lv, la, ll, waves; int small; };   // small: 14 KB of LDS per wave, two waves per SIMD
 inline LaneShape lane_shape_for(unsigned cls, int s_load)
 {
-    if (sizeof(real_t) != 8) return { 0, 0 };
-    // (what the 512 registers of a wave hold next to the solver: two sets of a 25-slot tile -- 200 registers --, one of a
-    // 50-slot tile; four sets compile to > 1 KB of scratch per lane)
-    if (s_load == 25) {
-        if (cls <= 64) return { 1, 1 };
-        if (cls <= 128) return { 2, 1 };
-        if (cls <= 256) return { 2, 2 };
-        if (cls <= 512) return { 2, 4 };
-    } else if (s_load == 50) {
-        if (cls <= 64) return { 1, 1 };
-        if (cls <= 128) return { 1, 2 };
-        if (cls <= 256) return { 1, 4 };
+    if (sizeof(real_t) != 8) return { 0, 0, 0, 0, 0 };
+    if (s_load == 25) {          // a set is 100 registers / 25.6 KB of LDS
+#ifndef PMF_LANE_A2
+#define PMF_LANE_A2 0   // rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
+                        // (measured, C3 A half, CG fp64: 22.3 ms against 20.0 -- the barrier per evaluation and the second copy of the
+                        // solver's chain cost more than the second wave per SIMD hides)
+#endif
+        if (cls <= 64) return { 1, 0, 0, 1, 1 };
+        if (cls <= 128) return PMF_LANE_A2 ? LaneShape{ 1, 0, 0, 2, 1 } : LaneShape{ 1, 0, 1, 1, 0 };
+        if (cls <= 256) return { 1, 2, 1, 1, 0 };
+        if (cls <= 512) return { 1, 2, 1, 2, 0 };
+        if (cls <= 1024) return { 1, 2, 1, 4, 0 };
+    } else if (s_load == 50) {   // a set is 200 registers / 51 KB of LDS
+        if (cls <= 64) return { 1, 0, 0, 1, 0 };
     }
-    return { 0, 0 };
+    return { 0, 0, 0, 0, 0 };
 }
 
 // Long-row path: rows above this many nonzeros get a whole workgroup of LONG_NW waves (row_eval.hpp, NW > 1).
@@ -191,7 +194,8 @@ int slots_per_lane(size_t k)
 struct OneLaunch {
     int reg_S, nw, s_load, spl;   // register-engine steps (0: LDS engine), waves per row, slots per factor row, slots per lane
     int team;                     // > 1: CUs per row (team launch)
-    int lane_L;                   // > 0: lane-per-nonzero engine with this many lane sets per wave (nw waves per row)
+    int lane_small;               // lane engine: the two-waves-per-SIMD flavour (lane_eval.hpp, SMALL_)
+    int lane_L, lane_A, lane_LL;  // lane_L > 0: lane-per-nonzero engine with this many lane sets per wave in VGPRs, AGPRs, LDS (nw waves per row)
     bool generic_only;
     hipStream_t main_stream, bin_stream, long_stream;
     size_t lds;

@@ -420,12 +420,12 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
 #endif
 }
 
-// Lane-per-nonzero engine (lane_eval.hpp): doubles, 25 or 50 slots per factor row; one wave per SIMD (the tile of two lane
-// sets is 200 architectural registers), NW waves per row.
-template <class T, int METHOD, int KS, int L, int NW>
-__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
+// Lane-per-nonzero engine (lane_eval.hpp): doubles, 25 or 50 slots per factor row; NW waves per row; one wave per SIMD, or
+// (SMALL: one register set, 14 KB of LDS per wave) two.
+template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL>
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(SMALL ? 2 : 1, SMALL ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
 {
-    using EV = LaneEval<T, KS, L, NW>;
+    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
     EV ev;
     sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
@@ -532,30 +532,35 @@ template <int M, int S> int launch_team(hipStream_t stream, int method, const Ha
 }
 
 // lane-per-nonzero launches (doubles only)
-template <int METHOD, int KS, int L, int NW> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (sizeof(real_t) == 8 && tu_has(METHOD) && METHOD != K_PG) {
-        using EV = LaneEval<real_t, KS, L, NW>;
-        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, L, NW>;
-        // workgroups per CU: one wave per SIMD, and the LDS each takes
-        const int occ = std::max(1, std::min(4 / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
+        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL>;
+        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL>;
+        // workgroups per CU: one (SMALL: two) waves per SIMD, and the LDS each takes
+        const int occ = std::max(1, std::min((SMALL ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
         const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)t_num_cu * (size_t)occ * grid_mult);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW), 0, stream, a);
         HIP_TRY(hipGetLastError());
         return 0;
     } else return 1;
 }
-template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int L, int nw, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
+    const int key = (((lv * 10 + la) * 10 + ll) * 10 + nw) * 10 + small;
     if (s_load == 25) {
-        if (L == 1 && nw == 1) return launch_lane<METHOD, 25, 1, 1>(stream, a, grid_mult);
-        if (L == 2 && nw == 1) return launch_lane<METHOD, 25, 2, 1>(stream, a, grid_mult);
-        if (L == 2 && nw == 2) return launch_lane<METHOD, 25, 2, 2>(stream, a, grid_mult);
-        if (L == 2 && nw == 4) return launch_lane<METHOD, 25, 2, 4>(stream, a, grid_mult);
+        switch (key) {
+            case 10011: return launch_lane<METHOD, 25, 1, 0, 0, 1, true>(stream, a, grid_mult);
+            case 10021: return launch_lane<METHOD, 25, 1, 0, 0, 2, true>(stream, a, grid_mult);
+            case 10110: return launch_lane<METHOD, 25, 1, 0, 1, 1>(stream, a, grid_mult);
+            case 12110: return launch_lane<METHOD, 25, 1, 2, 1, 1>(stream, a, grid_mult);
+            case 12120: return launch_lane<METHOD, 25, 1, 2, 1, 2>(stream, a, grid_mult);
+            case 12140: return launch_lane<METHOD, 25, 1, 2, 1, 4>(stream, a, grid_mult);
+        }
     } else if (s_load == 50) {
-        if (L == 1 && nw == 1) return launch_lane<METHOD, 50, 1, 1>(stream, a, grid_mult);
-        if (L == 1 && nw == 2) return launch_lane<METHOD, 50, 1, 2>(stream, a, grid_mult);
-        if (L == 1 && nw == 4) return launch_lane<METHOD, 50, 1, 4>(stream, a, grid_mult);
+        switch (key) {
+            case 10010: return launch_lane<METHOD, 50, 1, 0, 0, 1>(stream, a, grid_mult);
+        }
     }
     return 1;
 }
@@ -615,10 +620,13 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
     if (o.lane_L > 0) {
-        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.nw, a, o.grid_mult);
-        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.nw, a, o.grid_mult);
+        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
+        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
         return 1;
     }
+#ifdef PMF_LANE_ONLY   // development: compile the lane-per-nonzero kernels alone (seconds instead of minutes)
+    return rc;
+#else
     if (o.team > 1) {
         if (o.team == 2 && o.reg_S == 32) return launch_team<2, 32>(o.main_stream, method, a);
         if constexpr (PMF_TEAM_S36) { if (o.team == 2 && o.reg_S == 36) return launch_team<2, 36>(o.main_stream, method, a); }
@@ -651,6 +659,7 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
         case 2: rc = launch_method<2 * SLOT_ELEMS, 0>(o.bin_stream, method, a, o.lds, o.grid); break;
     }
     return rc;
+#endif
 }
 }  // namespace
 

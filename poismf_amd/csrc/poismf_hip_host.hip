@@ -188,6 +188,7 @@ struct Half {
     size_t dimM = 0, dimF = 0;
     size_t row_begin = 0, row_end = 0;  // shard
     size_t nnz = 0;
+    bool x_positive = false;            // every stored value > 0 (RowParams::x_pos)
     unsigned long long* d_indptr = nullptr;
     unsigned* d_indices = nullptr;
     real_t* d_values = nullptr;
@@ -254,6 +255,13 @@ __global__ __launch_bounds__(256) void rebase_indptr_kernel(unsigned long long* 
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) indptr[i] -= base;
 }
+// flag |= 1 when some stored value is not > 0 (zero, negative, NaN)
+__global__ __launch_bounds__(256) void values_positive_kernel(const real_t* v, size_t n, unsigned* flag)
+{
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) bad = bad || !(v[i] > (real_t)0);
+    if (bad) atomicOr(flag, 1u);
+}
 __global__ __launch_bounds__(256) void row_desc_kernel(const unsigned long long* indptr, const unsigned* perm, size_t n, RowDesc* desc)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -263,8 +271,8 @@ __global__ __launch_bounds__(256) void row_desc_kernel(const unsigned long long*
     }
 }
 
-// bin classes: multiples of 16 up to 256 nonzeros, multiples of 64 up to 1280 (the hand-overs between 1, 2, 4
-// and 8 waves per row fall on those), then powers of two.  The LDS tile of a launch is sized by the longest
+// bin classes: multiples of 16 up to 256 nonzeros, multiples of 64 up to 2048 (the hand-overs between 1, 2, 4
+// and 8 waves per row and between the team shapes fall on those), then powers of two.  The LDS tile of a launch is sized by the longest
 // row of its bin, and LDS is what limits the waves per CU, so fine classes where most rows live buy
 // occupancy (C2: 100 +- 10 nnz per row -> 7 waves per CU instead of 5).  Which ENGINE a row takes, and how
 // many waves share it, is decided by the class bound alone -- never by which other rows happen to be in the
@@ -272,8 +280,8 @@ __global__ __launch_bounds__(256) void row_desc_kernel(const unsigned long long*
 unsigned length_class(unsigned n)
 {
     if (n <= 256) return std::max(16u, (n + 15u) / 16u * 16u);
-    if (n <= 1280) return (n + 63u) / 64u * 64u;
-    unsigned cls = 2048;
+    if (n <= 2048) return (n + 63u) / 64u * 64u;   // (up to the longest team row: every class maps to ONE team shape, plan.hpp team_shape_for)
+    unsigned cls = 4096;
     while (cls < n) cls <<= 1;
     return cls;
 }
@@ -298,8 +306,18 @@ int finish_half(Half& h, hipStream_t stream, int nseg = 1)
     }
     const unsigned grid = (unsigned)std::min<size_t>((nloc + 255) / 256, 2048);
     hipLaunchKernelGGL(row_desc_kernel, dim3(grid), dim3(256), 0, stream, h.d_indptr, h.d_perm, nloc, h.d_desc);
+    // are all stored values positive (Poisson counts)?  One pass over the values, the flag rides in front of the lengths
+    unsigned* d_flag = nullptr;
+    HIP_TRY(pmf_alloc(&d_flag, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(unsigned), stream));
+    if (h.nnz > 0)
+        hipLaunchKernelGGL(values_positive_kernel, dim3((unsigned)std::min<size_t>((h.nnz + 255) / 256, 2048)), dim3(256), 0, stream, h.d_values, h.nnz, d_flag);
     std::vector<unsigned> len(nloc);
     hipError_t e = pmf_download(len.data(), d_len, sizeof(unsigned) * nloc, stream);
+    unsigned not_positive = 1;
+    if (e == hipSuccess) e = pmf_download(&not_positive, d_flag, sizeof(unsigned), stream);
+    h.x_positive = not_positive == 0;
+    pmf_free(d_flag, stream);
     pmf_free(d_len, stream);
     HIP_TRY(e);
     for (auto& sg : h.segs) {
@@ -835,6 +853,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     a.P.maxupd = (int)std::min<size_t>(p->maxupd, 0x7fffffff);
     a.P.limit_step = p->limit_step;
     a.P.max_cg_it = (int)std::max(1.0, std::min(50.0, (double)(real_t)s->k / 2.0));  // ref: src/poismf.c:342
+    static const bool no_prune = getenv("POISMF_HIP_NO_LS_PRUNE") != nullptr;  // testing knob: evaluate every line-search trial
+    a.P.x_pos = (h.x_positive && !no_prune) ? 1 : 0;
     a.reuse_prev = p->reuse_prev;
     a.early_stop = (p->method == POISMF_TNCG) && p->early_stop && (n_unchanged != nullptr || seg >= 0);
     a.n_unchanged = s->d_counter;
@@ -851,7 +871,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
     // solver) are merged into one launch.
-    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0; };
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0, lane_A = 0, lane_LL = 0, lane_small = 0; };
     std::vector<Launch> launches;
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots (32 for doubles, two slots per lane), and 24-bit row ids / 32-bit
@@ -885,13 +905,13 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
         if (lane_ok) {
             const LaneShape ls = lane_shape_for(b.cls, g.s_load);
-            if (ls.sets > 0) {
-                if (!launches.empty() && launches.back().lane_L == ls.sets && launches.back().nw == ls.waves &&
-                    launches.back().begin + launches.back().count == b.begin)
+            if (ls.waves > 0) {
+                if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small &&
+                    launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)
                     { launches.back().count += b.count; launches.back().nnz += b.nnz; }
                 else {
                     launches.push_back({ b.begin, b.count, g, ls.waves, 0, 0, b.nnz });
-                    launches.back().lane_L = ls.sets;
+                    launches.back().lane_L = ls.lv; launches.back().lane_A = ls.la; launches.back().lane_LL = ls.ll; launches.back().lane_small = ls.small;
                 }
                 continue;
             }
@@ -988,7 +1008,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             char txt[192];
             const char* m = is_pg ? "pg" : p->method == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
-            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,L=%d,NW=%d> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.nw, L.count);
+            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d,NW=%d%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.nw, L.lane_small ? ",2/SIMD" : "", L.count);
             else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
             else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
             else if (L.reg_S > 0) snprintf(txt, sizeof txt, "half_sweep_regw_kernel<%s,%s,S=%d,NW=%d> rows=%u;", t, m, L.reg_S, L.nw, L.count);
@@ -1033,7 +1053,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
             OneLaunch o;
-            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
+            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.lane_A = L.lane_A; o.lane_LL = L.lane_LL; o.lane_small = L.lane_small; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
             static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
             o.generic_only = generic_only;
             o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;

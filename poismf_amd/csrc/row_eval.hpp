@@ -112,6 +112,8 @@ template <class T> struct RowParams {
     int maxupd;
     int limit_step;
     int max_cg_it;               // TNC: max(1, min(50, k/2)), ref: src/poismf.c:342
+    int x_pos;                   // 1: every stored value of this half's matrix is > 0 (counts): the data term of the objective is
+                                 // concave along a line, which lets CG's line search skip trial steps that are certain to fail
 };
 
 __host__ __device__ inline size_t lds_bytes_per_wave(const TileGeom& g, size_t sizeof_real)
@@ -154,6 +156,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     static constexpr int SN = Slot<T>::N;
     static constexpr int NS = NC / SN;
     static constexpr bool PIPELINED = false;  // sweep_rows: no cross-row prefetch (the LDS tile has one set of index buffers)
+    static constexpr bool FUSED_SUMS = false;     // (lane_eval.hpp reduces the solvers' groups of dot products together)
     static constexpr bool MAY_CACHE = true;   // cached CG line search where the launch geometry has room for it (pq_cap)
     static constexpr int PRE = PMF_PRE;       // 16-byte slots per lane a prefetched chunk may take (19: 1216 slots = 19 KiB)
     static_assert(NC % SN == 0, "a lane holds whole 16-byte slots");

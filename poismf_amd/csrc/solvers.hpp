@@ -96,6 +96,36 @@ __device__ __forceinline__ T fun_and_grad(EV& ev, const RowParams<T>& P, const T
 }
 
 // ------------------------------------------------------------------------------------------------
+// Line-search trials that are certain to fail, without evaluating them.
+// The row objective is f(a) = r(a) - w sum_j x_j log(a . F_j) with r quadratic (Bsum . a + l2 a . a) and -- for x_j > 0, i.e.
+// counts -- a data term that is CONCAVE along any line; with `limit_step` the trial point is x + s d itself (feasible; only
+// components below 1e-15 are snapped to 0).  The tangent of the concave part at s = 0 therefore bounds f from below:
+//     f(x + s d) >= f(x) + s g.d + s^2 l2 d.d
+// A trial whose lower bound already misses the Armijo threshold f_cur - c s d.d by more than any rounding error fails in the
+// reference too (ref: src/nonnegcg.c:310-320: nfeval++, step *= decr): it is counted and skipped, no logarithm taken.  With
+// cg_iteration's l2 = 1e4 (poismf/__init__.py:250) that is every step above ~1e-4 -- the first five to seven of the ~six trials
+// an iteration takes from max_step <= 1 by factors of 4.  The last of the max_ls trials is always evaluated (quirk Q2 hands its
+// value on), and f_x is f at the current x even when f_cur is not (Q2 again).
+// Returns false when the evaluation budget runs out on the way (the reference returns from the row there, ref: :316-320).
+template <class T>
+__device__ __forceinline__ bool skip_certain_failures(T f_x, T f_cur, T gd, T l2dd, T dd, T c_ls, T decr, int max_ls, int maxnfeval,
+                                                      T& step, int& ls, int& nfeval)
+{
+    const T eps_m = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;   // >> the rounding error of any of these objective values
+    const T marg = eps_m * (T)(d_abs((double)f_x) + d_abs((double)f_cur));
+    while (ls < max_ls - 1) {
+        const T lb = fma_t(step * step, l2dd, fma_t(step, gd, f_x));
+        const T thr = f_cur - c_ls * step * dd;
+        if (!(lb > thr + marg)) break;
+        nfeval++;
+        if (nfeval >= maxnfeval) return false;
+        step *= decr;
+        ls++;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Non-negative Polak-Ribiere CG (Li 2013)                        ref: src/nonnegcg.c:177-346
 // ------------------------------------------------------------------------------------------------
 template <class EV, class T, int NC>
@@ -110,8 +140,10 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
     T gprev_sq = (T)0;
     T f_cur = fun_single(ev, P, bsum, x);                          // ref: :191
     T f_new = (T)0;
+    T f_x = f_cur;                                                 // f at the current x (f_cur may be a refused point's value, quirk Q2)
     int nfeval = 1;
     if (not_finite(f_cur)) return;                                 // ref: :223-226, row left unchanged
+    const bool prune = P.x_pos != 0 && P.limit_step != 0;
 
     for (int it = 0; it < maxiter; it++) {
         grad_single(ev, P, bsum, x, g, weighted);                  // ref: :231
@@ -145,7 +177,9 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
 
         const T dd = ev.dot(d, d);                                 // ref: :295
         T step = max_step;
-        for (int ls = 0; ls < max_ls; ls++) {                      // ref: :297-327
+        int ls = 0;
+        if (prune && !skip_certain_failures(f_x, f_cur, gd, P.l2 * dd, dd, c_ls, decr, max_ls, maxnfeval, step, ls, nfeval)) return;
+        for (; ls < max_ls; ls++) {                                // ref: :297-327
             PMF_EW {
                 trial[i] = fma_t(step, d[i], x[i]);
                 if (P.limit_step) trial[i] = ((double)trial[i] >= 1e-15) ? trial[i] : (T)0;   // quirk Q10
@@ -154,6 +188,7 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
             f_new = fun_single(ev, P, bsum, trial);
             if (!not_finite(f_new) && f_new <= f_cur - c_ls * step * dd) {
                 PMF_EW x[i] = trial[i];
+                f_x = f_new;
                 break;
             }
             nfeval++;                                              // quirk Q3: failed trials only
@@ -212,8 +247,10 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         }
     }
     T f_new = (T)0;
+    T f_x = f_cur;            // f at the current x (f_cur may be a refused point's value, quirk Q2)
     int nfeval = 1;
     if (not_finite(f_cur)) return;
+    const bool prune = P.x_pos != 0;   // (this variant runs with limit_step only)
 
     bool p_current = false;   // the cached p is T.x for the current x, to rounding (advanced by a step the cache could be trusted for)
     auto grad_pass = [&](T (&gg)[NC]) {
@@ -249,6 +286,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
             }
         }
         PMF_EW d[i] = (x[i] <= (T)0 && g[i] >= (T)0) ? (T)0 : -g[i];
+        T gg_now = (T)0;   // g . g of this iteration's gradient (FUSED_SUMS: reduced together with theta / beta)
         if (it > 0) {
             T th = (T)0, be = (T)0;
             PMF_EW {
@@ -256,12 +294,35 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
                 th += on ? g[i] * dp[i] : (T)0;
                 be += on ? g[i] * (g[i] - gp[i]) : (T)0;
             }
-            T theta = ev.rsum(th), beta = ev.rsum(be);
+            T theta, beta;
+            if constexpr (EV::FUSED_SUMS) {
+                T v3[3] = { th, be, (T)0 };
+                PMF_EW v3[2] = ev.act[i] ? fma_t(g[i], g[i], v3[2]) : v3[2];
+                ev.template rsum_n<3>(v3);
+                theta = v3[0]; beta = v3[1]; gg_now = v3[2];
+            } else {
+                theta = ev.rsum(th); beta = ev.rsum(be);
+            }
             theta /= gprev_sq;
             beta /= gprev_sq;
             PMF_EW d[i] += (x[i] <= (T)0) ? (T)0 : beta * dp[i] - theta * (g[i] - gp[i]);
         }
-        const T gd = ev.dot(g, d);
+        T gd, dd;
+        if constexpr (EV::FUSED_SUMS) {
+            // g . d and d . d together (and, in the first iteration, g . g with them)
+            T v3[3] = { (T)0, (T)0, (T)0 };
+            PMF_EW {
+                v3[0] = ev.act[i] ? fma_t(g[i], d[i], v3[0]) : v3[0];
+                v3[1] = ev.act[i] ? fma_t(d[i], d[i], v3[1]) : v3[1];
+                v3[2] = ev.act[i] ? fma_t(g[i], g[i], v3[2]) : v3[2];
+            }
+            if (it == 0) { ev.template rsum_n<3>(v3); gg_now = v3[2]; }
+            else { T v2[2] = { v3[0], v3[1] }; ev.template rsum_n<2>(v2); v3[0] = v2[0]; v3[1] = v2[1]; }
+            gd = v3[0]; dd = v3[1];
+        } else {
+            gd = ev.dot(g, d);
+            dd = (T)0;
+        }
         if (d_abs((double)gd) <= (double)tol) return;
 
         T m = (T)1;
@@ -274,7 +335,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         (void)ev.template eval<false, false>((T)0, dummy, ev.qbuf);
         if constexpr (PK) { ev.unpark(0, x); ev.unpark(5, bs); ev.unpark(1, g); ev.unpark(2, d); }
 
-        const T dd = ev.dot(d, d);
+        if constexpr (!EV::FUSED_SUMS) dd = ev.dot(d, d);
         T step = max_step;
         bool accepted = false;
         // (the log-likelihood terms of LS_BATCH consecutive trial steps come from one call: teams of CUs pay one exchange per
@@ -282,23 +343,45 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         constexpr int LSB = EV::LS_BATCH;
         double lsv[LSB];
         bool lst[LSB];
-        for (int ls = 0; ls < max_ls; ls++) {
-            if (ls % LSB == 0) ev.logsum_cached_batch(step, decr, lsv, lst);
+        int ls = 0;
+        if (prune && !skip_certain_failures(f_x, f_cur, gd, P.l2 * dd, dd, c_ls, decr, max_ls, maxnfeval, step, ls, nfeval)) return;
+        for (int bpos = 0; ls < max_ls; ls++, bpos++) {
+            if constexpr (!EV::FUSED_SUMS) { if (bpos % LSB == 0) ev.logsum_cached_batch(step, decr, lsv, lst); }
             PMF_EW {
                 trial[i] = fma_t(step, d[i], x[i]);
                 trial[i] = ((double)trial[i] >= 1e-15) ? trial[i] : (T)0;
             }
-            T r = ev.dot(bs, trial);
-            r += P.l2 * ev.dot(trial, trial);
-            double lsum_here = lsv[0];
-            bool trusted = lst[0];
+            T r;
+            double lsum_here = 0.0;
+            bool trusted = true;
+            if constexpr (EV::FUSED_SUMS) {
+                // Bsum . trial, trial . trial and the log-likelihood terms of the trial in ONE reduction
+                bool bad;
+                T v3[3] = { (T)0, (T)0, (T)ev.logsum_cached_lane(step, bad) };
+                PMF_EW {
+                    v3[0] = ev.act[i] ? fma_t(bs[i], trial[i], v3[0]) : v3[0];
+                    v3[1] = ev.act[i] ? fma_t(trial[i], trial[i], v3[1]) : v3[1];
+                }
+                ev.template rsum_n<3>(v3);
+                trusted = __builtin_amdgcn_ballot_w64(bad) == 0;
+                r = v3[0];
+                r += P.l2 * v3[1];
+                lsum_here = ev.combine_scalar(trusted ? (double)v3[2] : __builtin_nan(""));
+                trusted = !(lsum_here != lsum_here);
+            } else {
+                r = ev.dot(bs, trial);
+                r += P.l2 * ev.dot(trial, trial);
+                lsum_here = lsv[0];
+                trusted = lst[0];
 #pragma unroll
-            for (int j = 1; j < LSB; j++)
-                if (ls % LSB == j) { lsum_here = lsv[j]; trusted = lst[j]; }
+                for (int j = 1; j < LSB; j++)
+                    if (bpos % LSB == j) { lsum_here = lsv[j]; trusted = lst[j]; }
+            }
             f_new = r - (T)lsum_here * P.w;
             if (!trusted) f_new = fun_single(ev, P, bs, trial);   // a prediction cancelled to ~0: evaluate at the snapped point
             if (!not_finite(f_new) && f_new <= f_cur - c_ls * step * dd) {
                 PMF_EW x[i] = trial[i];
+                f_x = f_new;
                 accepted = true;
                 p_current = trusted;
                 if constexpr (EV::CACHED_GRAD) { if (trusted) ev.advance_cached(step); }
@@ -310,7 +393,8 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         }
         if (!accepted) p_current = false;   // (x did not move, but the cache may hold a refused trial's history: recompute)
         f_cur = f_new;
-        gprev_sq = ev.dot(g, g);
+        if constexpr (EV::FUSED_SUMS) gprev_sq = gg_now;
+        else gprev_sq = ev.dot(g, g);
         if constexpr (PK) { ev.park(3, g); ev.park(4, d); }
         else { PMF_EW { gp[i] = g[i]; dp[i] = d[i]; } }
     }
