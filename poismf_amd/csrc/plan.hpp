@@ -13,10 +13,25 @@
 
 using namespace pmf;
 
+// The reference's ABI has one failure code (1, "out of memory", ref: src/poismf.c:498-504).  The callers of this library get
+// that code for every failure too, but stderr says what happened: the last HIP error of the calling thread is kept here
+// and the entry points print the reference's message only when it was an allocation that failed.
+inline hipError_t& pmf_last_hip_error()
+{
+    static thread_local hipError_t e = hipSuccess;
+    return e;
+}
+inline void pmf_report_failure()
+{
+    const hipError_t e = pmf_last_hip_error();
+    if (e == hipSuccess || e == hipErrorOutOfMemory) fprintf(stderr, "Error: out of memory.\n");   // ref: src/poismf.c:501
+    else fprintf(stderr, "Error: the HIP device or runtime failed (%s) -- not an out-of-memory condition; the factors are not valid.\n", hipGetErrorString(e));
+}
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
+            pmf_last_hip_error() = e_;                                                             \
             fprintf(stderr, "poismf_hip: %s failed: %s\n", #expr, hipGetErrorString(e_));          \
             return 1;                                                                              \
         }                                                                                          \
@@ -43,7 +58,9 @@ template <class T> struct HalfArgs {
     unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
     unsigned* eval_rows;              // != nullptr (profiling sessions): [local row] += passes over that row's tile
     unsigned long long* team_buf;     // team launches (several CUs per row, reg_eval.hpp M_ > 1): arrival counters, mailboxes, exchange slots
-    unsigned* team_err;               // set by a team launch that gave up (an exchange timed out); sticky until the session reads it
+    unsigned* team_err;               // set by a team launch that gave up (an exchange timed out); the host re-runs such a launch
+    unsigned team_spin;               // polls (~1 us each) before a team member gives the launch up (TEAM_SPIN_LIMIT; a knob for tests)
+    const unsigned* gate;             // != nullptr: the kernel runs only if *gate != 0 (the streamed re-run of a team launch that gave up)
 };
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };

@@ -107,6 +107,8 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
 template <class EV, class T, int NC, int METHOD, int NW>
 __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
 {
+    // (the streamed re-run of a team launch: only if that launch gave up)
+    if (a.gate != nullptr && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     ev.init(a.geom, a.F, smem);
     T bs[NC];
     ev.load_vec(a.bsum, bs);
@@ -312,21 +314,27 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
     __syncthreads();
     ev.team_words = a.team_buf + TEAM_HEAD_WORDS + (size_t)team * TEAM_WORDS;
     ev.team_err = err;
+    ev.team_spin = a.team_spin;
     unsigned long long* mail = ev.team_words;                 // [2]: { ticket, row number } of the row with that parity
     unsigned long long* here = ev.team_words + 2;             // [M_MAX]: member m has arrived
     constexpr unsigned END = 0xffffffffu;
     if (ev.member != 0 && threadIdx.x == 0) gran_store(here + ev.member, 1ull);
 
-    // leader: wait for the team, or for the rows to run out
+    // leader: wait for the team, or for the rows to run out.  A team that stays incomplete (a full-size grid leaves up to M - 1
+    // workgroups per XCD without partners) is no error while other teams are draining the queue; if the queue does not move for
+    // `team_spin` polls either, nothing is making progress: give the launch up (the host re-runs its rows on the streamed path).
     if (ev.member == 0) {
         if (threadIdx.x == 0) {
             unsigned full = 0;
+            unsigned seen = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (unsigned spins = 0; !full; spins++) {
                 full = 1;
                 for (int m = 1; m < M; m++) full &= gran_load(here + m) != 0ull;
                 if (full) break;
-                if (__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.nrows || spins > TEAM_SPIN_LIMIT ||
-                    __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                const unsigned q = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q >= a.nrows || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (q != seen) { seen = q; spins = 0; }
+                if (spins > a.team_spin) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             box[0] = full;
@@ -350,11 +358,19 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
                 gran_store(mail + (rowno_next & 1u), ((unsigned long long)rowno_next << 32) | (box[0] < a.nrows ? box[0] : END));
             }
         } else if (threadIdx.x == 0) {
+            // (a member of a team that is still incomplete waits for its FIRST ticket as long as other teams keep the queue moving:
+            // its leader posts the end-of-rows ticket once the rows run out)
             unsigned long long v = 0;
+            unsigned seen = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (unsigned spins = 0;; spins++) {
                 v = gran_load(mail + (rowno_next & 1u));
                 if ((unsigned)(v >> 32) == rowno_next) break;
-                if (spins > TEAM_SPIN_LIMIT || ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if ((spins & 255u) == 255u) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { v = END; break; }
+                    const unsigned q = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (rowno_next == 1u && q != seen) { seen = q; spins = 0; }
+                }
+                if (spins > a.team_spin) {
                     __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v = END;
                     break;

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "plan.hpp"
@@ -227,8 +228,10 @@ struct poismf_hip_session {
     unsigned* d_counter = nullptr;
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
-    unsigned* d_team_err = nullptr;         // sticky error word of the team launches
-    bool team_launched = false;             // since the error word was last read
+    unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far
+    real_t* d_team_backup = nullptr;        // the rows a team launch starts from (restored before its re-run)
+    size_t team_backup_elems = 0;
+    bool team_launched = false;             // since the words were last read
     int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
     bool profiling = false;
     std::vector<ProfRec> prof;
@@ -255,6 +258,34 @@ __global__ __launch_bounds__(256) void rebase_indptr_kernel(unsigned long long* 
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) indptr[i] -= base;
 }
+// ---- a team launch that gives up must not cost the fit (reg_eval.hpp, M_ > 1: an exchange between CUs timed out) -----------
+// The rows a team launch covers are saved first; if the launch sets the error word, they are put back and the same rows run
+// on the streamed LDS kernel (gated on that word, so the healthy case pays three empty launches and one copy of the rows).
+__global__ __launch_bounds__(256) void team_save_rows_kernel(const real_t* M, const RowDesc* desc, unsigned nrows, unsigned row_offset, int k, real_t* backup)
+{
+    const size_t n = (size_t)nrows * (size_t)k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (size_t)k, c = i % (size_t)k;
+        backup[i] = M[(size_t)(row_offset + desc[r].lrow) * (size_t)k + c];
+    }
+}
+__global__ __launch_bounds__(256) void team_restore_rows_kernel(real_t* M, real_t* Mp, int ldM, const RowDesc* desc, unsigned nrows, unsigned row_offset,
+                                                                int k, const real_t* backup, const unsigned* err)
+{
+    if (*err == 0) return;
+    const size_t n = (size_t)nrows * (size_t)k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (size_t)k, c = i % (size_t)k;
+        const size_t row = (size_t)(row_offset + desc[r].lrow);
+        M[row * (size_t)k + c] = backup[i];
+        if (Mp != nullptr) Mp[row * (size_t)ldM + c] = backup[i];
+    }
+}
+__global__ void team_fold_err_kernel(unsigned* err)
+{
+    if (err[0] != 0) { err[1] += 1; err[0] = 0; }
+}
+
 // flag |= 1 when some stored value is not > 0 (zero, negative, NaN)
 __global__ __launch_bounds__(256) void values_positive_kernel(const real_t* v, size_t n, unsigned* flag)
 {
@@ -538,9 +569,9 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     if (pmf_alloc(&s->d_bsum, k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 8), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads)
-    if (pmf_alloc(&s->d_team_err, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (hipMemsetAsync(s->d_team_err, 0, sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 16), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs)
+    if (pmf_alloc(&s->d_team_err, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (cached_stream(device, &s->aux_stream)) return fail();
     if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) return fail();
     if (hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail();
@@ -657,6 +688,7 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     pmf_free(s->d_queue, s->stream);
     pmf_free(s->d_team, s->stream);
     pmf_free(s->d_team_err, s->stream);
+    pmf_free(s->d_team_backup, s->stream);
     (void)hipStreamSynchronize(s->stream);   // the stream-ordered frees have run
     if (aux) release_stream(s->device, aux);
     if (own) release_stream(s->device, own);
@@ -712,13 +744,13 @@ int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, 
 static int team_check(poismf_hip_session* s)
 {
     if (!s->team_launched) return 0;
-    unsigned err = 0;
-    HIP_TRY(pmf_download(&err, s->d_team_err, sizeof(unsigned), s->stream));
+    unsigned w[2] = { 0, 0 };
+    HIP_TRY(pmf_download(w, s->d_team_err, 2 * sizeof(unsigned), s->stream));
     s->team_launched = false;
-    if (err != 0) {
-        fprintf(stderr, "poismf_hip: a multi-CU row launch gave up (code %u)\n", err);
-        (void)hipMemsetAsync(s->d_team_err, 0, sizeof(unsigned), s->stream);
-        return 1;
+    if (w[1] != 0) {
+        fprintf(stderr, "poismf_hip: %u multi-CU row launch(es) timed out waiting for a partner CU and were re-run on the streamed path "
+                        "(results are valid; another process or kernel is holding CUs)\n", w[1]);
+        HIP_TRY(hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream));
     }
     return 0;
 }
@@ -1043,7 +1075,20 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             HIP_TRY(hipMemsetAsync(s->d_team, 0, (size_t)TEAM_BUF_BYTES, s->stream));
             a.team_buf = s->d_team;
             s->team_launched = true;
+            // the rows this launch starts from, in case it gives up
+            const size_t need = (size_t)L.count * s->k;
+            if (need > s->team_backup_elems) {
+                pmf_free(s->d_team_backup, s->stream);
+                s->d_team_backup = nullptr; s->team_backup_elems = 0;
+                HIP_TRY(pmf_alloc(&s->d_team_backup, need * sizeof(real_t), s->stream));
+                s->team_backup_elems = need;
+            }
+            hipLaunchKernelGGL(team_save_rows_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, (size_t)s->num_cu * 8)), dim3(256), 0, s->stream,
+                               M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, s->d_team_backup);
         }
+        a.gate = nullptr;
+        static const unsigned team_spin = getenv("POISMF_HIP_TEAM_SPIN_LIMIT") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_TEAM_SPIN_LIMIT"))) : TEAM_SPIN_LIMIT;   // testing knob
+        a.team_spin = team_spin;
         unsigned grid_mult = one_wave_reg ? 32 : 2;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
@@ -1069,6 +1114,26 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 HIP_TRY(hipEventRecord(lr.t0, lst));
             }
             rc = launch_one(p->method, o, a);
+            if (!rc && L.team > 1) {
+                // if the team launch gave up: rows back to where they started, the same rows on the streamed LDS kernel, note it
+                hipLaunchKernelGGL(team_restore_rows_kernel, dim3((unsigned)std::min<size_t>(((size_t)L.count * s->k + 255) / 256, (size_t)s->num_cu * 8)),
+                                   dim3(256), 0, s->stream, M, Mp, (int)s->ld, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k,
+                                   s->d_team_backup, s->d_team_err);
+                HalfArgs<real_t> af = a;
+                // (a.geom is the LDS engine's geometry for the launch's longest length class: what these rows take without teams)
+                af.team_buf = nullptr;
+                af.gate = s->d_team_err;
+                af.queue = s->d_queue + MAX_LAUNCHES + 8 + (launch_no % 8);
+                HIP_TRY(hipMemsetAsync(af.queue, 0, sizeof(unsigned), s->stream));
+                OneLaunch of = o;
+                of.reg_S = 0; of.nw = 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0;
+                of.s_load = af.geom.s_load;
+                of.bin_stream = s->stream;
+                of.lds = lds_bytes_per_block(af.geom, sizeof(real_t), 1);
+                of.grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / of.lds)) * 2);
+                rc = launch_one(p->method, of, af);
+                hipLaunchKernelGGL(team_fold_err_kernel, dim3(1), dim3(1), 0, s->stream, s->d_team_err);
+            }
             if (s->profiling) {
                 HIP_TRY(hipEventRecord(lr.t1, lst));
                 s->lprof.push_back(lr);
@@ -1274,7 +1339,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
             if (tn_stop) stopped_earlyB = ((double)unchanged / (double)s->dimB) >= .95;  // ref: :401-403 (quirk Q7)
         }
         if (method == POISMF_PG) step_size *= 0.5;  // ref: :532-533
-        if (hipStreamSynchronize(s->stream) != hipSuccess) return 1;
+        HIP_TRY(hipStreamSynchronize(s->stream));
         if (g_should_stop) break;
 
         // ---- A half ----
@@ -1283,11 +1348,159 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
             if (poismf_hip_half_sweep(s, 1, &p, step_size, cnst_div, tn_stop ? &unchanged : nullptr)) return 1;
             if (tn_stop) stopped_earlyA = ((double)unchanged / (double)s->dimA) >= .95;
         }
-        if (hipStreamSynchronize(s->stream) != hipSuccess) return 1;
+        HIP_TRY(hipStreamSynchronize(s->stream));
         if (stopped_earlyA && stopped_earlyB) break;
     }
     return team_check(s);
 }
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+// Several GPUs behind the same C-ABI: POISMF_HIP_DEVICES=0,1,..,7 makes run_poismf cut the rows of A and of B into
+// one contiguous, nnz-balanced range per listed device (ref: the row loops it shards are src/poismf.c:159-162, :296-299,
+// :352-358), keep one session per device -- its shard of the CSR / CSC, both factors replicated -- and alternate with one host
+// thread per device.  After a half every device holds the rows it updated; they travel DIRECTLY to every peer, device to
+// device (hipMemcpyPeerAsync on the owner's stream: over xGMI's full mesh all seven links of a GPU carry one shard each at the
+// same time; no staging, no collective to wait for the slowest rank), and the next half starts when all of them have landed.
+// The k-vector column sums are recomputed by every device from its replica (deterministic, identical bits everywhere), which
+// is what replaces the north-star's all-reduce; TNCG's early-stop counter is summed on the host.
+// A device may be listed more than once (POISMF_HIP_DEVICES=0,0): the shards then share that GPU, which is how the one-GPU
+// test exercises every line of this path (tests/test_gpu_multi.py); results equal the single-session run bit for bit, since a
+// row's arithmetic depends on its length class alone and the column sums are computed in one fixed order.
+// -------------------------------------------------------------------------------------------------
+namespace {
+
+struct Range { size_t lo, hi; };
+// contiguous row ranges with (nearly) equal nonzero counts: cuts at the nnz quantiles of the row pointers
+std::vector<Range> balanced_ranges(const sparse_ix* indptr, size_t n, size_t parts)
+{
+    std::vector<Range> out;
+    const unsigned long long total = (unsigned long long)indptr[n];
+    size_t prev = 0;
+    for (size_t pidx = 1; pidx <= parts; pidx++) {
+        size_t cut = n;
+        if (pidx < parts) {
+            const unsigned long long target = total * pidx / parts;
+            cut = (size_t)(std::lower_bound(indptr, indptr + n + 1, (sparse_ix)target) - indptr);
+            cut = std::min(std::max(cut, prev), n);
+        }
+        out.push_back({ prev, cut });
+        prev = cut;
+    }
+    return out;
+}
+
+template <class Fn> int on_every_device(size_t n, Fn&& fn)
+{
+    std::vector<int> rc(n, 0);
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < n; d++) th.emplace_back([&, d]() { rc[d] = fn(d); });
+    rc[0] = fn(0);
+    for (auto& t : th) t.join();
+    for (int r : rc) if (r) return r;
+    return 0;
+}
+
+int run_poismf_multi(const std::vector<int>& devices, real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indices, real_t* B, real_t* Xc,
+                     sparse_ix* Xc_indptr, sparse_ix* Xc_indices, size_t dimA, size_t dimB, size_t k, const poismf_hip_params& p, size_t numiter)
+{
+    const size_t nd = devices.size();
+    const std::vector<Range> rA = balanced_ranges(Xr_indptr, dimA, nd), rB = balanced_ranges(Xc_indptr, dimB, nd);
+    std::vector<poismf_hip_session*> ss(nd, nullptr);
+    std::vector<hipEvent_t> done(nd, nullptr);       // device d's rows of the half just run have reached every peer
+    auto cleanup = [&]() {
+        for (size_t d = 0; d < nd; d++) {
+            if (done[d]) { (void)hipSetDevice(devices[d]); (void)hipEventDestroy(done[d]); }
+            poismf_hip_session_destroy(ss[d]);
+        }
+    };
+    int rc = on_every_device(nd, [&](size_t d) -> int {
+        if (poismf_hip_session_create(&ss[d], devices[d], nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k,
+                                      rA[d].lo, rA[d].hi, rB[d].lo, rB[d].hi)) return 1;
+        if (poismf_hip_session_set_factors(ss[d], A, B)) return 1;
+        HIP_TRY(hipEventCreateWithFlags(&done[d], hipEventDisableTiming));
+        for (size_t q = 0; q < nd; q++)   // peer access where the pair allows it (the copies below work without, through the host)
+            if (devices[q] != devices[d]) { int can = 0; if (hipDeviceCanAccessPeer(&can, devices[d], devices[q]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[q], 0); }
+        (void)hipGetLastError();
+        return 0;
+    });
+    if (rc) { cleanup(); return 1; }
+
+    const int method = p.method;
+    real_t step_size = p.step_size;
+    const bool tn_stop = (method == POISMF_TNCG) && p.early_stop;
+    bool stopped_earlyA = false, stopped_earlyB = false;
+    // one half on every device, then the exchange: owner d sends rows [lo, hi) of the updated factor to every peer
+    auto half = [&](int which, real_t step, real_t cnst_div, size_t* unchanged_total) -> int {
+        const std::vector<Range>& rr = which ? rA : rB;
+        std::vector<size_t> unchanged(nd, 0);
+        int r = on_every_device(nd, [&](size_t d) -> int {
+            if (poismf_hip_half_sweep(ss[d], which, &p, step, cnst_div, tn_stop ? &unchanged[d] : nullptr)) return 1;
+            HIP_TRY(hipSetDevice(devices[d]));
+            const size_t bytes = (rr[d].hi - rr[d].lo) * k * sizeof(real_t);
+            real_t* mine = (which ? ss[d]->dA : ss[d]->dB) + rr[d].lo * k;
+            for (size_t q = 0; q < nd && bytes > 0; q++) {
+                if (q == d) continue;
+                real_t* theirs = (which ? ss[q]->dA : ss[q]->dB) + rr[d].lo * k;
+                HIP_TRY(hipMemcpyPeerAsync(theirs, devices[q], mine, devices[d], bytes, ss[d]->stream));
+            }
+            HIP_TRY(hipEventRecord(done[d], ss[d]->stream));
+            return 0;
+        });
+        if (r) return r;
+        // nobody reads the factor before every owner's rows have landed in its replica; the gather copies are re-derived
+        r = on_every_device(nd, [&](size_t d) -> int {
+            HIP_TRY(hipSetDevice(devices[d]));
+            for (size_t q = 0; q < nd; q++)
+                if (q != d) HIP_TRY(hipStreamWaitEvent(ss[d]->stream, done[q], 0));
+            if (nd > 1) poismf_hip_session_factors_dirty(ss[d], which);
+            HIP_TRY(hipStreamSynchronize(ss[d]->stream));
+            return 0;
+        });
+        if (unchanged_total) { *unchanged_total = 0; for (size_t u : unchanged) *unchanged_total += u; }
+        return r;
+    };
+    for (size_t it = 0; it < numiter && !rc; it++) {
+        if (g_should_stop) break;
+        const real_t cnst_div = 1. / (1. + 2. * p.l2_reg * step_size);                      // quirk Q6
+        if (!(method == POISMF_TNCG && stopped_earlyB)) {                                   // B half first (quirk Q5)
+            size_t unchanged = 0;
+            rc = half(0, step_size, cnst_div, &unchanged);
+            if (tn_stop) stopped_earlyB = ((double)unchanged / (double)dimB) >= .95;        // ref: src/poismf.c:401-403
+        }
+        if (method == POISMF_PG) step_size *= 0.5;                                          // ref: :532-533
+        if (rc || g_should_stop) break;
+        if (!(method == POISMF_TNCG && stopped_earlyA)) {
+            size_t unchanged = 0;
+            rc = half(1, step_size, cnst_div, &unchanged);
+            if (tn_stop) stopped_earlyA = ((double)unchanged / (double)dimA) >= .95;
+        }
+        if (stopped_earlyA && stopped_earlyB) break;
+    }
+    if (!rc) rc = poismf_hip_session_get_factors(ss[0], A, B);   // every replica holds the same bits
+    cleanup();
+    return rc ? 1 : 0;
+}
+
+// POISMF_HIP_DEVICES: comma-separated device ids; empty / one entry: the single-device path
+std::vector<int> devices_from_env()
+{
+    std::vector<int> out;
+    const char* e = getenv("POISMF_HIP_DEVICES");
+    if (e == nullptr) return out;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return out;
+    for (const char* q = e; *q;) {
+        char* end = nullptr;
+        const long v = strtol(q, &end, 10);
+        if (end == q) break;
+        if (v >= 0 && v < n) out.push_back((int)v);
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',' && *end != 0) break;
+    }
+    return out;
+}
+
 }  // namespace
 
 // run_poismf's loop on a session that already holds X and the starting factors (PoisMF.fit keeps the CSR / CSC it
@@ -1296,9 +1509,10 @@ int poismf_hip_session_run(poismf_hip_session* s, const poismf_hip_params* p, si
 {
     SigintScope sig;
     sig.enter();
+    pmf_last_hip_error() = hipSuccess;
     int ret_code = 0;
     if (hipSetDevice(s->device) != hipSuccess || run_alternation(s, *p, numiter)) {
-        fprintf(stderr, "Error: out of memory.\n");
+        pmf_report_failure();
         ret_code = 1;
     }
     return sig.leave(ret_code, handle_interrupt != 0);
@@ -1313,6 +1527,7 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     (void)nthreads;
     SigintScope sig;
     sig.enter();
+    pmf_last_hip_error() = hipSuccess;
 
     int ret_code = 0;
     poismf_hip_session* s = nullptr;
@@ -1323,6 +1538,17 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     p.l2_reg = l2_reg; p.l1_reg = l1_reg; p.w_mult = w_mult; p.step_size = step_size;
     p.method = method; p.limit_step = limit_step; p.maxupd = maxupd;
     p.early_stop = early_stop; p.reuse_prev = reuse_prev;
+    {   // several GPUs of this node (POISMF_HIP_DEVICES=0,1,..): same call, same results, rows sharded over the devices
+        const std::vector<int> devs = devices_from_env();
+        if (devs.size() > 1) {
+            if (run_poismf_multi(devs, A, Xr, Xr_indptr, Xr_indices, B, Xc, Xc_indptr, Xc_indices, dimA, dimB, k, p, numiter)) {
+                pmf_report_failure();
+                ret_code = 1;
+            }
+            return sig.leave(ret_code, handle_interrupt);
+        }
+        if (devs.size() == 1) device = devs[0];
+    }
     // POISMF_HIP_VERBOSE=1: wall time of the phases of this call on stderr (development aid, scripts/time_abi.py)
     static const bool verbose = getenv("POISMF_HIP_VERBOSE") != nullptr;
     double t[5] = { 0, 0, 0, 0, 0 };
@@ -1338,7 +1564,7 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     bad = bad || poismf_hip_session_get_factors(s, A, B);
     t[4] = now();
     if (bad) {
-        fprintf(stderr, "Error: out of memory.\n");  // ref: :501
+        pmf_report_failure();   // "Error: out of memory." (ref: :501) only when it was one
         ret_code = 1;
     }
     poismf_hip_session_destroy(s);
@@ -1404,7 +1630,7 @@ int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* 
         if (!rc) rc = team_check(s);
     }
     poismf_hip_session_destroy(s);
-    if (rc) fprintf(stderr, "Error: out of memory.\n");
+    if (rc) pmf_report_failure();
     return rc ? 1 : 0;
 }
 

@@ -216,6 +216,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     // team state (M > 1)
     unsigned long long* team_words;   // this team's words of HalfArgs::team_buf
     unsigned* team_err;               // != 0: some exchange of this launch timed out, give up
+    unsigned team_spin = TEAM_SPIN_LIMIT;   // polls before giving up
     T* team_tot;                      // LDS: the team's totals
     int member;                       // 0 .. M - 1 (0 when M == 1)
     unsigned xseq;                    // exchanges so far
@@ -430,7 +431,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
                             const bool ok = (a0 >> 32) == xseq && (a1 >> 32) == xseq && (l0 >> 32) == xseq && (l1 >> 32) == xseq;
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                             __builtin_amdgcn_s_sleep(1);
-                            if ((++spins & 255u) == 0 && (spins > TEAM_SPIN_LIMIT || __hip_atomic_load(team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            if ((++spins & 255u) == 0 && (spins > team_spin || __hip_atomic_load(team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                                 if (lane == 0) __hip_atomic_store(team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 break;
                             }

@@ -1,0 +1,40 @@
+"""Several devices behind run_poismf() itself (poismf_hip_host.hip, run_poismf_multi): POISMF_HIP_DEVICES lists them, the rows of A
+and of B are cut into one nnz-balanced range per entry, every entry gets a session with its shard and replicas of both factors,
+and after each half the updated rows travel device to device.  One GPU is what a test box has, so the list names it twice or
+three times: every line of the path runs (shards, host threads, peer copies, events, re-padding, the summed early-stop counter);
+what cannot be shown here is only that the copies cross xGMI.  Results must equal the single-session call bit for bit.
+Needs an MI355X."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from tests import helpers as H
+from tests.test_gpu_parity import gpu_run
+csr, csc, A0, B0 = H.small_problem(1500, 900, 60000, {k}, {prec}, seed=8, powerlaw=True, empty_rows=(5,))
+A, B, _ = gpu_run(csr, csc, A0, B0, {method!r}, 3, {k}, **{kw!r})
+np.save({out!r}, np.concatenate([A.ravel().astype(np.float64), B.ravel().astype(np.float64)]))
+"""
+
+
+@pytest.mark.parametrize("method,prec,k,kw", [("pg", True, 50, {}), ("cg", False, 50, {}), ("cg", True, 20, {}),
+                                              ("tncg", False, 20, dict(maxupd=60, early_stop=True))])
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_run_poismf_over_a_device_list_equals_the_single_device_call(tmp_path, method, prec, k, kw, devices):
+    res = {}
+    for tag, env in (("one", {}), ("many", {"POISMF_HIP_DEVICES": devices})):
+        out = str(tmp_path / f"{tag}.npy")
+        e = dict(os.environ); e.pop("POISMF_HIP_DEVICES", None); e.update(env)
+        subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, method=method, prec=prec, k=k, kw=kw)], check=True, env=e,
+                       cwd=ROOT, timeout=600)
+        res[tag] = np.load(out)
+    assert np.isfinite(res["one"]).all()
+    assert np.array_equal(res["one"], res["many"])

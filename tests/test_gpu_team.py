@@ -133,3 +133,21 @@ def test_segments_and_bin_company_do_not_change_team_rows():
         s.close()
     assert np.isfinite(res[0]).all()
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+
+
+def test_a_team_launch_that_gives_up_is_rerun_on_the_streamed_path(tmp_path):
+    """POISMF_HIP_TEAM_SPIN_LIMIT=1 makes team leaders give up at once (their partner CU has not arrived within two polls): the
+    launch sets the error word, the host puts the rows back where they started and runs them on the streamed LDS kernel.
+    The call still returns 0, says so on stderr, and the factors equal those of POISMF_HIP_NO_TEAM=1 (the same kernel on the
+    same rows from the same starting point)."""
+    res, err = {}, {}
+    for tag, env in (("gave_up", {"POISMF_HIP_TEAM_SPIN_LIMIT": "1"}), ("streamed", {"POISMF_HIP_NO_TEAM": "1"})):
+        out = str(tmp_path / f"{tag}.npy")
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out)], check=True, env=e, cwd=ROOT, timeout=600,
+                           capture_output=True, text=True)
+        res[tag], err[tag] = np.load(out), r.stderr
+    assert "re-run on the streamed path" in err["gave_up"], err["gave_up"]
+    assert "out of memory" not in err["gave_up"]
+    assert np.isfinite(res["gave_up"]).all()
+    assert np.array_equal(res["gave_up"], res["streamed"])
