@@ -1368,6 +1368,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
 // test exercises every line of this path (tests/test_gpu_multi.py); results equal the single-session run bit for bit, since a
 // row's arithmetic depends on its length class alone and the column sums are computed in one fixed order.
 // -------------------------------------------------------------------------------------------------
+extern "C++" {
 namespace {
 
 struct Range { size_t lo, hi; };
@@ -1502,6 +1503,7 @@ std::vector<int> devices_from_env()
 }
 
 }  // namespace
+}  // extern "C++"
 
 // run_poismf's loop on a session that already holds X and the starting factors (PoisMF.fit keeps the CSR / CSC it
 // built on the device and never takes them through host memory).  Same return codes as run_poismf.
