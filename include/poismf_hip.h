@@ -261,6 +261,17 @@ POISMF_HIP_API size_t poismf_hip_session_plan(poismf_hip_session *s, int which, 
  * what its algorithmic bytes are computed from).  Same buffer convention as poismf_hip_session_plan.  Reporting only. */
 POISMF_HIP_API size_t poismf_hip_session_launch_profile(poismf_hip_session *s, int which, char *buf, size_t cap);
 
+/* Profiling sessions also record what every row's inner solver decided in the most recent half-sweep of half `which`:
+ * out[2 r] = iterations | rc << 24, out[2 r + 1] = evaluations, for local row r -- the numbers the reference's
+ * minimize_nonneg_cg (niter, nfeval; ref src/nonnegcg.c:177-189) and tnc (nfeval, niter, rc; ref src/tnc.c:251-260) return and
+ * cg_iteration / tncg_iteration discard.  Testing aid: pins the solvers' decisions, not only their results. */
+POISMF_HIP_API int poismf_hip_session_decisions(poismf_hip_session *s, int which, unsigned *out, size_t nrows);
+/* factors_multiple (below / ref src/pred.c:66-199) that also returns those two words per row. */
+POISMF_HIP_API int poismf_hip_factors_multiple_decisions(real_t *A, real_t *B, real_t *Bsum, real_t *Amean, real_t *Xr,
+                          sparse_ix *Xr_indptr, sparse_ix *Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult,
+                          real_t step_size, size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean,
+                          unsigned *decisions);
+
 /* Number of nonzeros held by this session for half `which` (shard only). */
 POISMF_HIP_API size_t poismf_hip_session_nnz(poismf_hip_session *s, int which);
 

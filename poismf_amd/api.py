@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_nnz", "poismf_hip_selftest_log", "poismf_hip_session_eval_stats",
     "poismf_hip_session_create_coo", "poismf_hip_session_stream", "poismf_hip_session_factors_dirty", "poismf_hip_session_run",
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
-    "poismf_hip_session_launch_profile",
+    "poismf_hip_session_launch_profile", "poismf_hip_session_decisions", "poismf_hip_factors_multiple_decisions",
     "poismf_hip_session_predict", "poismf_hip_session_topn",
 )
 
@@ -66,6 +66,10 @@ def load_library(use_float):
     lib.run_poismf.restype = i
     lib.factors_multiple.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, i]
     lib.factors_multiple.restype = i
+    lib.poismf_hip_factors_multiple_decisions.argtypes = [vp] * 7 + [i, sz, r, r, r, sz, sz, i, C.c_bool, C.c_bool, vp]
+    lib.poismf_hip_factors_multiple_decisions.restype = i
+    lib.poismf_hip_session_decisions.argtypes = [vp, i, vp, sz]
+    lib.poismf_hip_session_decisions.restype = i
     lib.predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
     lib.predict_multiple.restype = None
     lib.topN.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz, i]
@@ -237,6 +241,26 @@ def _predict_factors_multiple(B, Bsum, Amean, Xr_indptr, Xr_indices, Xr, l2_reg=
     if ret:
         raise MemoryError("Could not allocate enough memory.")                      # ref: pxi:205-206
     return A
+
+
+def factors_multiple_with_decisions(B, Bsum, Amean, Xr_indptr, Xr_indices, Xr, l2_reg=1e9, w_mult=1., step_size=1e-7,
+                                    niter=10, maxupd=1, method="tncg", limit_step=0, reuse_mean=1):
+    """_predict_factors_multiple plus what each row's solver decided: returns (A, iterations, evaluations, rc) -- the
+    numbers the reference's minimize_nonneg_cg / tnc hand back (testing aid, include/poismf_hip.h)."""
+    use_float = B.dtype == np.float32
+    _check_arrays(use_float, (B, Bsum, Amean, Xr), (Xr_indptr, Xr_indices))
+    lib = load_library(use_float)
+    k = B.shape[1]
+    dimA = Xr_indptr.shape[0] - 1
+    A = np.empty((dimA, k), dtype=B.dtype)
+    dec = np.zeros((dimA, 2), dtype=np.uint32)
+    ret = lib.poismf_hip_factors_multiple_decisions(_ptr(A), _ptr(B), _ptr(Bsum), _ptr(Amean), _ptr(Xr) if Xr.shape[0] else None,
+                                                    _ptr(Xr_indptr), _ptr(Xr_indices) if Xr_indices.shape[0] else None, k, dimA, l2_reg,
+                                                    w_mult, step_size, int(niter), int(maxupd), _METHOD.get(method, 1), bool(limit_step),
+                                                    bool(reuse_mean), _ptr(dec))
+    if ret:
+        raise MemoryError("Could not allocate enough memory.")
+    return A, (dec[:, 0] & 0xffffff).astype(np.int64), dec[:, 1].astype(np.int64), (dec[:, 0] >> 24).astype(np.int64)
 
 
 class PoisMF:
@@ -476,6 +500,15 @@ class Session:
         if self.lib.poismf_hip_session_eval_stats(self.h, int(which), C.byref(a), C.byref(b)):
             raise RuntimeError("poismf_hip_session_eval_stats failed")
         return a.value, b.value
+
+    def decisions(self, which):
+        """(iterations, evaluations, rc) per row of this session's shard of half `which` (0: B rows, 1: A rows) in the most recent
+        half-sweep since profile(True) -- what the reference's minimize_nonneg_cg / tnc return and its drivers drop"""
+        lo, hi = self.shardA if which else self.shardB
+        dec = np.zeros((hi - lo, 2), dtype=np.uint32)
+        if self.lib.poismf_hip_session_decisions(self.h, int(which), _ptr(dec), hi - lo):
+            raise RuntimeError("poismf_hip_session_decisions: profiling is off")
+        return (dec[:, 0] & 0xffffff).astype(np.int64), dec[:, 1].astype(np.int64), (dec[:, 0] >> 24).astype(np.int64)
 
     def nnz(self, which):
         return self.lib.poismf_hip_session_nnz(self.h, int(which))

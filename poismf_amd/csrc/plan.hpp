@@ -57,6 +57,7 @@ template <class T> struct HalfArgs {
     unsigned* n_unchanged;
     unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
     unsigned* eval_rows;              // != nullptr (profiling sessions): [local row] += passes over that row's tile
+    unsigned* dec_rows;               // != nullptr (profiling sessions): [2 x local row] = the solver's decisions (solvers.hpp, SolveStats)
     unsigned long long* team_buf;     // team launches (several CUs per row, reg_eval.hpp M_ > 1): arrival counters, mailboxes, exchange slots
     unsigned* team_err;               // set by a team launch that gave up (an exchange timed out); the host re-runs such a launch
     unsigned team_spin;               // polls (~1 us each) before a team member gives the launch up (TEAM_SPIN_LIMIT; a knob for tests)

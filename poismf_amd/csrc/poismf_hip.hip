@@ -69,19 +69,20 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
         }
     }
 
+    SolveStats st;
     if constexpr (METHOD == K_PG) {
         pg_row(ev, a.P, x, shift);
     } else if constexpr (METHOD == K_CG) {
         // cached line search: streamed rows of the LDS engine (plan_geom decides), fp64 single-wave rows of the register engine
         if constexpr (EV::MAY_CACHE) {
-            if (a.P.limit_step && ev.pq_cap > 0 && nnz <= (unsigned)ev.pq_cap) cg_row_cached(ev, a.P, shift, x, weighted);
-            else cg_row(ev, a.P, shift, x, weighted);
-        } else cg_row(ev, a.P, shift, x, weighted);
+            if (a.P.limit_step && ev.pq_cap > 0 && nnz <= (unsigned)ev.pq_cap) cg_row_cached(ev, a.P, shift, x, weighted, st);
+            else cg_row(ev, a.P, shift, x, weighted, st);
+        } else cg_row(ev, a.P, shift, x, weighted, st);
     } else {
         T prev[NC];
         PMF_EW prev[i] = x[i];
         if (!a.reuse_prev) { PMF_EW x[i] = (T)1e-3; }                   // ref: src/poismf.c:379-381
-        (void)Tnc<T, NC, EV>::minimize(ev, a.P, shift, x);
+        (void)Tnc<T, NC, EV>::minimize(ev, a.P, shift, x, st);
         if (a.early_stop) {                                             // ref: src/poismf.c:393-396
             PMF_EW prev[i] = prev[i] - x[i];
             const T moved = ev.dot(prev, prev);
@@ -95,6 +96,11 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
 #ifndef PMF_PROBE
     if (a.eval_rows != nullptr && ev.lane == 0 && ev.wid == 0 && ev.member == 0) a.eval_rows[lrow] += ev.n_eval;
 #endif
+    // the solver's decisions for this row (tests/test_gpu_decisions.py): { iterations | rc << 24, evaluations as the reference counts them }
+    if (a.dec_rows != nullptr && ev.lane == 0 && ev.wid == 0 && ev.member == 0) {
+        a.dec_rows[2 * (size_t)lrow] = (unsigned)st.niter | ((unsigned)st.rc << 24);
+        a.dec_rows[2 * (size_t)lrow + 1] = (unsigned)st.nfeval;
+    }
 }
 
 // A wavefront (or, NW > 1, a workgroup of NW wavefronts) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the

@@ -196,6 +196,7 @@ struct Half {
     unsigned* d_perm = nullptr;
     RowDesc* d_desc = nullptr;
     unsigned* d_eval_rows = nullptr;      // per local row: passes over its tile while profiling (allocated on demand)
+    unsigned* d_dec_rows = nullptr;       // per local row: { iterations | rc << 24, evaluations } of its solver while profiling
     // The shard's rows are cut into contiguous SEGMENTS (one unless the multi-GPU driver asks for more, so that a
     // segment's rows can travel while the next one computes); within a segment rows are sorted by length and binned.
     struct Segment { unsigned row_lo, row_hi; std::vector<Bin> bins; };
@@ -249,6 +250,7 @@ void free_half(Half& h, hipStream_t stream)
     pmf_free(h.d_perm, stream);
     pmf_free(h.d_desc, stream);
     pmf_free(h.d_eval_rows, stream);
+    pmf_free(h.d_dec_rows, stream);
     h = Half();
 }
 
@@ -775,6 +777,8 @@ void poismf_hip_session_profile(poismf_hip_session* s, int enable)
         const size_t n = h.row_end - h.row_begin;
         if (s->profiling && h.d_eval_rows == nullptr && n > 0 && pmf_alloc(&h.d_eval_rows, sizeof(unsigned) * n, s->stream) != hipSuccess) h.d_eval_rows = nullptr;
         if (h.d_eval_rows != nullptr) (void)hipMemsetAsync(h.d_eval_rows, 0, sizeof(unsigned) * n, s->stream);
+        if (s->profiling && h.d_dec_rows == nullptr && n > 0 && pmf_alloc(&h.d_dec_rows, 2 * sizeof(unsigned) * n, s->stream) != hipSuccess) h.d_dec_rows = nullptr;
+        if (h.d_dec_rows != nullptr) (void)hipMemsetAsync(h.d_dec_rows, 0, 2 * sizeof(unsigned) * n, s->stream);
     }
 }
 
@@ -811,6 +815,16 @@ int poismf_hip_session_eval_stats(poismf_hip_session* s, int which, unsigned lon
         *tile_passes += ev[i];
         *nnz_passes += (unsigned long long)ev[i] * (ptr[i + 1] - ptr[i]);
     }
+    return 0;
+}
+
+// The decisions of the solver on every row of half `which` in the most recent half-sweep of a profiling session: out[2 r] =
+// iterations | rc << 24, out[2 r + 1] = evaluations, counted as the reference's minimize_nonneg_cg / tnc count them (local row r).
+int poismf_hip_session_decisions(poismf_hip_session* s, int which, unsigned* out, size_t nrows)
+{
+    Half& h = s->half[which ? 1 : 0];
+    if (h.d_dec_rows == nullptr) return 1;
+    HIP_TRY(pmf_download(out, h.d_dec_rows, 2 * sizeof(unsigned) * std::min(nrows, h.row_end - h.row_begin), s->stream));
     return 0;
 }
 
@@ -891,6 +905,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     a.early_stop = (p->method == POISMF_TNCG) && p->early_stop && (n_unchanged != nullptr || seg >= 0);
     a.n_unchanged = s->d_counter;
     a.eval_rows = s->profiling ? h.d_eval_rows : nullptr;
+    a.dec_rows = s->profiling ? h.d_dec_rows : nullptr;
     if (a.early_stop && prologue) HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(unsigned), s->stream));
 
     const bool single_pass = is_pg && p->maxupd <= 1 && !weighted;
@@ -1579,11 +1594,30 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
 // -------------------------------------------------------------------------------------------------
 // factors_multiple: latent factors of new rows with B fixed          ref: src/pred.c:66-199
 // -------------------------------------------------------------------------------------------------
+static int factors_multiple_impl(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* Xr, sparse_ix* Xr_indptr,
+                                 sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, real_t step_size,
+                                 size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean, unsigned* decisions);
 int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* Xr, sparse_ix* Xr_indptr,
                      sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, real_t step_size,
                      size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean, int nthreads)
 {
     (void)nthreads;
+    return factors_multiple_impl(A, B, Bsum, Amean, Xr, Xr_indptr, Xr_indices, k, dimA, l2_reg, w_mult, step_size, niter, maxupd, method,
+                                 limit_step, reuse_mean, nullptr);
+}
+// Testing aid: factors_multiple that also hands back every row's solver decisions (2 words per row, see
+// poismf_hip_session_decisions) -- how the golden single-row fixtures pin the device's iteration / evaluation counts.
+int poismf_hip_factors_multiple_decisions(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* Xr, sparse_ix* Xr_indptr,
+                                          sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, real_t step_size,
+                                          size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean, unsigned* decisions)
+{
+    return factors_multiple_impl(A, B, Bsum, Amean, Xr, Xr_indptr, Xr_indices, k, dimA, l2_reg, w_mult, step_size, niter, maxupd, method,
+                                 limit_step, reuse_mean, decisions);
+}
+static int factors_multiple_impl(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* Xr, sparse_ix* Xr_indptr,
+                                 sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, real_t step_size,
+                                 size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean, unsigned* decisions)
+{
     const size_t ks = (size_t)k;
     const size_t nnz = Xr_indptr[dimA];
     // rows start at the mean of the fitted A, except TNCG without reuse_mean (1e-3, set in the kernel); ref: :144-147
@@ -1607,6 +1641,7 @@ int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* 
         hipMemcpy(s->dB, B, dimB * ks * sizeof(real_t), hipMemcpyHostToDevice) != hipSuccess) {
         rc = 1;
     } else {
+        if (decisions != nullptr) poismf_hip_session_profile(s, 1);
         poismf_hip_params p;
         p.l2_reg = l2_reg; p.l1_reg = 0; p.w_mult = w_mult; p.step_size = step_size;
         p.method = method; p.limit_step = limit_step; p.maxupd = maxupd;
@@ -1630,6 +1665,7 @@ int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* 
                     hipMemcpy(A, s->dA, dimA * ks * sizeof(real_t), hipMemcpyDeviceToHost) != hipSuccess))
             rc = 1;
         if (!rc) rc = team_check(s);
+        if (!rc && decisions != nullptr) rc = poismf_hip_session_decisions(s, 1, decisions, dimA);
     }
     poismf_hip_session_destroy(s);
     if (rc) pmf_report_failure();

@@ -20,6 +20,12 @@ namespace pmf {
 
 template <class T> __device__ __forceinline__ bool not_finite(T v) { return isnan(v) || isinf(v); }
 
+// What a row's solver decided, for tests that pin the decisions and not only the result (the reference hands the same numbers
+// back from minimize_nonneg_cg -- niter, nfeval, ref: src/nonnegcg.c:177-189 -- and from tnc -- nfeval, niter, rc, ref:
+// src/tnc.c:251-260; cg_iteration / tncg_iteration drop them).  CG rc: 0 |g.d| <= tol, 1 evaluation budget, 2 iteration
+// budget, 3 f(x0) not finite.  Wave-uniform scalars; written to memory only in profiling sessions.
+struct SolveStats { int niter = 0, nfeval = 0, rc = 0; };
+
 // ------------------------------------------------------------------------------------------------
 // Proximal gradient
 // ------------------------------------------------------------------------------------------------
@@ -130,7 +136,7 @@ __device__ __forceinline__ bool skip_certain_failures(T f_x, T f_cur, T gd, T l2
 // ------------------------------------------------------------------------------------------------
 template <class EV, class T, int NC>
 __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC],
-                                       bool weighted)
+                                       bool weighted, SolveStats& st)
 {
     const T tol = (T)1e-2, decr = (T)0.25, c_ls = (T)0.01;         // ref: src/poismf.c:318-319
     const int maxnfeval = 150, max_ls = 20;
@@ -142,10 +148,12 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
     T f_new = (T)0;
     T f_x = f_cur;                                                 // f at the current x (f_cur may be a refused point's value, quirk Q2)
     int nfeval = 1;
-    if (not_finite(f_cur)) return;                                 // ref: :223-226, row left unchanged
+    int it = 0;
+    auto leave = [&](int rc) { st.niter = it; st.nfeval = nfeval; st.rc = rc; };
+    if (not_finite(f_cur)) { leave(3); return; }                   // ref: :223-226, row left unchanged
     const bool prune = P.x_pos != 0 && P.limit_step != 0;
 
-    for (int it = 0; it < maxiter; it++) {
+    for (it = 0; it < maxiter; it++) {
         grad_single(ev, P, bsum, x, g, weighted);                  // ref: :231
         PMF_EW d[i] = (x[i] <= (T)0 && g[i] >= (T)0) ? (T)0 : -g[i];   // ref: :236-239
         if (it > 0) {                                              // ref: :242-261
@@ -161,7 +169,7 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
             PMF_EW d[i] += (x[i] <= (T)0) ? (T)0 : beta * dp[i] - theta * (g[i] - gp[i]);
         }
         const T gd = ev.dot(g, d);                                 // ref: :264-269
-        if (d_abs((double)gd) <= (double)tol) return;
+        if (d_abs((double)gd) <= (double)tol) { leave(0); return; }
 
         T max_step;                                                // ref: :272-288
         if (P.limit_step) {
@@ -178,7 +186,7 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
         const T dd = ev.dot(d, d);                                 // ref: :295
         T step = max_step;
         int ls = 0;
-        if (prune && !skip_certain_failures(f_x, f_cur, gd, P.l2 * dd, dd, c_ls, decr, max_ls, maxnfeval, step, ls, nfeval)) return;
+        if (prune && !skip_certain_failures(f_x, f_cur, gd, P.l2 * dd, dd, c_ls, decr, max_ls, maxnfeval, step, ls, nfeval)) { leave(1); return; }
         for (; ls < max_ls; ls++) {                                // ref: :297-327
             PMF_EW {
                 trial[i] = fma_t(step, d[i], x[i]);
@@ -192,13 +200,14 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
                 break;
             }
             nfeval++;                                              // quirk Q3: failed trials only
-            if (nfeval >= maxnfeval) return;
+            if (nfeval >= maxnfeval) { leave(1); return; }
             step *= decr;
         }
         f_cur = f_new;                                             // quirk Q2, ref: :328
         gprev_sq = ev.dot(g, g);                                   // ref: :332
         PMF_EW { gp[i] = g[i]; dp[i] = d[i]; }
     }
+    leave(2);
 }
 
 // The same solver with the line search evaluated from cached predictions.  With limit_step the trial point
@@ -209,7 +218,7 @@ __device__ __forceinline__ void cg_row(EV& ev, const RowParams<T>& P, const T (&
 // instead of ~6.  Arithmetic differs from the direct evaluation by rounding only (p + alpha q vs a fresh dot).
 template <class EV, class T, int NC>
 __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC],
-                                              bool weighted)
+                                              bool weighted, SolveStats& st)
 {
     const T tol = (T)1e-2, decr = (T)0.25, c_ls = (T)0.01;
     const int maxnfeval = 150, max_ls = 20;
@@ -249,7 +258,9 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
     T f_new = (T)0;
     T f_x = f_cur;            // f at the current x (f_cur may be a refused point's value, quirk Q2)
     int nfeval = 1;
-    if (not_finite(f_cur)) return;
+    int it = 0;
+    auto leave = [&](int rc) { st.niter = it; st.nfeval = nfeval; st.rc = rc; };
+    if (not_finite(f_cur)) { leave(3); return; }
     const bool prune = P.x_pos != 0;   // (this variant runs with limit_step only)
 
     bool p_current = false;   // the cached p is T.x for the current x, to rounding (advanced by a step the cache could be trusted for)
@@ -262,7 +273,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         }
         ev.template eval<false, true>((T)-1, gg, ev.pbuf);
     };
-    for (int it = 0; it < maxiter; it++) {
+    for (it = 0; it < maxiter; it++) {
         if (it > 0) {
             // gradient at x.  Register engine: after a trusted step the coefficients x_j / p_j come from the cached
             // p = T.x + alpha T.d -- the backward half of a pass; differs from fresh dot products by rounding only, and p is at
@@ -323,7 +334,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
             gd = ev.dot(g, d);
             dd = (T)0;
         }
-        if (d_abs((double)gd) <= (double)tol) return;
+        if (d_abs((double)gd) <= (double)tol) { leave(0); return; }
 
         T m = (T)1;
         PMF_EW if (ev.act[i] && d[i] < (T)0) m = (T)d_min((double)m, (double)(-x[i] / d[i]));
@@ -344,7 +355,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         double lsv[LSB];
         bool lst[LSB];
         int ls = 0;
-        if (prune && !skip_certain_failures(f_x, f_cur, gd, P.l2 * dd, dd, c_ls, decr, max_ls, maxnfeval, step, ls, nfeval)) return;
+        if (prune && !skip_certain_failures(f_x, f_cur, gd, P.l2 * dd, dd, c_ls, decr, max_ls, maxnfeval, step, ls, nfeval)) { leave(1); return; }
         for (int bpos = 0; ls < max_ls; ls++, bpos++) {
             if constexpr (!EV::FUSED_SUMS) { if (bpos % LSB == 0) ev.logsum_cached_batch(step, decr, lsv, lst); }
             PMF_EW {
@@ -388,7 +399,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
                 break;
             }
             nfeval++;
-            if (nfeval >= maxnfeval) return;
+            if (nfeval >= maxnfeval) { leave(1); return; }
             step *= decr;
         }
         if (!accepted) p_current = false;   // (x did not move, but the cache may hold a refused trial's history: recompute)
@@ -398,6 +409,7 @@ __device__ __forceinline__ void cg_row_cached(EV& ev, const RowParams<T>& P, con
         if constexpr (PK) { ev.park(3, g); ev.park(4, d); }
         else { PMF_EW { gp[i] = g[i]; dp[i] = d[i]; } }
     }
+    leave(2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,7 +858,7 @@ template <class T, int NC, class EV> struct Tnc {
     }
 
     // ref: tnc :251-463 + tnc_minimize :554-993 with tncg_iteration's arguments (src/poismf.c:383-391)
-    static __device__ __forceinline__ int minimize(EV& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC])
+    static __device__ __forceinline__ int minimize(EV& ev, const RowParams<T>& P, const T (&bsum)[NC], T (&x)[NC], SolveStats& st)
     {
         ST s;
         s.nfeval = 0;
@@ -855,7 +867,7 @@ template <class T, int NC, class EV> struct Tnc {
         const int n = ev.k;
 
         PMF_EW x[i] = (x[i] < (T)0.) ? (T)0. : x[i];                      // coercex, ref: :323
-        if (s.maxnfeval < 1) return T_MAXFUN;
+        if (s.maxnfeval < 1) { st.rc = T_MAXFUN; return T_MAXFUN; }
         T f = fun_and_grad(ev, P, bsum, x, s.gfull);                      // ref: :341
         s.nfeval++;
         PMF_EW {                                                          // ref: :383-399 (Q9)
@@ -877,6 +889,7 @@ template <class T, int NC, class EV> struct Tnc {
         T fLastReset, fLastConstraint, yrsr = 0.0, yksk = 0.0, alpha = 0.0;
         bool upd1 = true, newcon = true, lreset = false, remcon;
         int icycle = n - 1, rc;
+        int niter = 0;
         T temp[NC];
 
         PMF_EW if (s.xscale[i] > 0.0) x[i] = (x[i] - s.xoffset[i]) / s.xscale[i];     // scalex, ref: :492-501
@@ -980,6 +993,7 @@ template <class T, int NC, class EV> struct Tnc {
                 if (!added && s.nfeval == oldnfeval) { rc = T_NOPROGRESS; break; }
                 fLastConstraint = f;
             }
+            niter++;                                                      // (tnc_minimize's own iteration count)
 
             difold = difnew;
             difnew = oldf - f;
@@ -1041,6 +1055,7 @@ template <class T, int NC, class EV> struct Tnc {
         }
 
         unscale_clamp(s, x);                                              // ref: :971-972
+        st.niter = niter; st.nfeval = s.nfeval; st.rc = rc;
         return rc;
     }
 };

@@ -156,6 +156,8 @@ def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True):
     stats = {}
     try:
         s.set_factors(A0, B0)
+        if method == "cg":
+            s.profile(True)        # the row kernels then record every row's (iterations, evaluations, rc)
         p = s.make_params(method, l2, maxupd=maxupd, reuse_prev=reuse_prev)
         step = s.real(1e-7)
         cnst_div = s.cnst_div(l2, step)
@@ -165,6 +167,7 @@ def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True):
             if which == 1 and method == "pg":
                 step = s.real(step * 0.5)
             s.half_sweep(which, p, step, cnst_div)
+            dec = s.decisions(which) if method == "cg" else None
             A1, B1 = s.get_factors()
             M1, F = (A1, prevB) if which else (B1, prevA)
             Mprev = prevA if which else prevB
@@ -205,6 +208,20 @@ def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True):
                         worst = np.argsort(-np.abs(fo - fr) / np.maximum(np.abs(fr), 1e-300))[:5]
                         for r in worst:
                             print(f"   half {which} row {rows[r]} nnz {lens[r]}: objective gpu {fo[r]:.12g} oracle {fr[r]:.12g}")
+            if dec is not None:
+                # the solver's decisions on the sampled rows against the checker's minimize_nonneg_cg (ref: src/nonnegcg.c:177-346)
+                ip = sptr.astype(np.int64)
+                same, dnf = 0, []
+                for j, r in enumerate(rows):
+                    xv, xi = np.ascontiguousarray(sd[ip[j]:ip[j + 1]]), np.ascontiguousarray(si[ip[j]:ip[j + 1]])
+                    if len(xv) == 0:
+                        same += 1
+                        continue
+                    _, _, ni_r, nf_r, rc_r = orc.cg_row(Mprev[r], F, bs_exact, xv, xi, l2, 1.0, maxupd, True)
+                    same += (int(dec[0][r]), int(dec[1][r]), int(dec[2][r])) == (int(ni_r), int(nf_r), int(rc_r))
+                    dnf.append(abs(int(dec[1][r]) - int(nf_r)))
+                stats[f"dec_same{which}"] = same / len(rows)
+                stats[f"dec_dnfeval{which}"] = float(np.mean(dnf)) if dnf else 0.0
             # invariants over the WHOLE factor
             empty = _row_lengths(trip, which) == 0
             assert not M1[empty].any()
@@ -229,6 +246,7 @@ def test_c3_cg_fp64_fullsize(c4_trip):
     st = _fullsize_halves(c4_trip, 50, "cg", False, None)
     assert max(st["err0"], st["err1"]) <= 1e-3          # CG fp64 element-wise (measured 1.5e-10)
     assert max(st["obj0"], st["obj1"]) <= 1e-8          # measured 1e-14
+    assert min(st["dec_same0"], st["dec_same1"]) >= 0.99   # the checker's (iterations, evaluations, rc) row for row
 
 
 @pytest.mark.parametrize("maxupd", [None, 1])
@@ -246,6 +264,8 @@ def test_c4_cg_fp32_fullsize(c4_trip):
     end up to 20 % apart in objective, the sample's total within 4e-3 (B half, measured 3.9e-3) / 1e-5 (A half)."""
     st = _fullsize_halves(c4_trip, 50, "cg", True, None)
     assert st["obj0"] <= 1e-2 and st["obj1"] <= 1e-4
+    # fp32 decisions: the same number of line-search trials within one per row on average (rows flip a backtracking step)
+    assert max(st["dec_dnfeval0"], st["dec_dnfeval1"]) <= 1.5
 
 
 @pytest.fixture(scope="module")
