@@ -153,7 +153,8 @@ POISMF_HIP_API int poismf_hip_session_create(
 /* The same session built from HOST COO triplets (what PoisMF._process_data holds, ref: poismf/__init__.py:404-414):
  * both orientations are converted on the device (duplicates summed, indices sorted, section 1c) and stay there -- the
  * CSR / CSC never exist in host memory.  Only triplets whose row lies in [rowA_begin,rowA_end) enter the CSR shard and
- * only those whose column lies in [rowB_begin,rowB_end) the CSC shard.  Requires n < 2^32. */
+ * only those whose column lies in [rowB_begin,rowB_end) the CSC shard.  Requires n < 2^32.  Returns 0; 1 out of memory / no
+ * device; 3 when a row or column index lies outside the matrix (it would become a gather offset into the factors). */
 POISMF_HIP_API int poismf_hip_session_create_coo(
     poismf_hip_session **out, int device, void *stream,
     const sparse_ix *row, const sparse_ix *col, const real_t *val, size_t n,

@@ -373,6 +373,8 @@ class Session:
             rc = self.lib.poismf_hip_session_create_coo(
                 C.byref(h), int(device), C.c_void_p(stream or 0), _ptr(row), _ptr(col), _ptr(val), len(val),
                 self.dimA, self.dimB, self.k, self.shardA[0], self.shardA[1], self.shardB[0], self.shardB[1])
+            if rc == 3:
+                raise ValueError("a row / column index of the triplets lies outside the matrix")
         else:
             _check_arrays(use_float, (csr[0], csc[0]), (csr[1], csr[2], csc[1], csc[2]))
             if len(csr[0]) == 0:

@@ -66,6 +66,18 @@ template <int W> __device__ __forceinline__ double swap_fold(double a, double b)
     return __builtin_bit_cast(double, ((unsigned long long)hi0 << 32) | lo0) + __builtin_bit_cast(double, ((unsigned long long)hi1 << 32) | lo1);
 }
 
+template <int W> __device__ __forceinline__ float swap_fold(float a, float b)
+{
+    const unsigned ab = __builtin_bit_cast(unsigned, a), bb = __builtin_bit_cast(unsigned, b);
+    if constexpr (W == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(ab, bb, false, false);
+        return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane16_swap(ab, bb, false, false);
+        return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+}
+
 // Nothing moves across this line: neither loads at the IR / instruction-selection level (the memory clobber; a bare
 // sched_barrier is no obstacle there, and hipcc then requests a whole pass's LDS reads at once and parks their 200 destination
 // registers -- in practice: the tile -- in AGPRs) nor anything in the machine scheduler.
@@ -92,8 +104,12 @@ __device__ __forceinline__ unsigned acc_get(unsigned a)
 
 // SMALL_: one staging buffer, shared with the transpose scratch (14 KB of LDS per wave: eight waves per CU, two per SIMD, for
 // kernels whose registers allow that -- one set in architectural registers, nothing in AGPRs)
-template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false> struct LaneEval {
-    static_assert(sizeof(T) == 8, "the lane-per-nonzero engine is instantiated for doubles");
+// PF_: while a row is being solved, the NEXT row's whole tile (and its values) is requested into accumulator registers that
+// nothing else uses (global_load_dwordx4 straight into AGPR quads, lane by lane as the direct loads of gather()); the switch to
+// the next row is then 200 v_accvgpr_reads and 25 ds_write_b128 instead of a trip to memory.  A row's gather runs at the
+// fabric's gather ceiling (C3: 40 GB per half = 6.7 ms at 6 TB/s) and, at one wave per SIMD, nothing else overlapped it: it
+// was a third of the half.  (One architectural set + one LDS set, one wave per row: what rows of 65 .. 128 nonzeros take.)
+template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false> struct LaneEval {
     using SA = typename Slot<T>::A;
     static constexpr int SN = Slot<T>::N;                 // elements per 16-byte slot
     static constexpr int KP = KS * SN;                    // elements of a factor row, padded to whole slots
@@ -103,19 +119,34 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr int W = KS < 13 ? KS : 13;           // slots per staged chunk (row stride of the LDS image: 13 slots = 52 banks, conflict-free b128 reads)
     static constexpr int NCH = (KS + W - 1) / W;          // chunks per factor row; chunk c starts at slot min(c W, KS - W)
     static constexpr int STAGE_BYTES = WAVE * W * 16;
-    static constexpr int NBUF = LL_ > 0 ? LL_ * NCH : (SMALL_ ? 1 : 2);  // staging buffers; the chunks of the LDS sets stay in theirs
-    static constexpr bool ALIAS = SMALL_;
+#ifndef PMF_LANE_DIRECT
+#define PMF_LANE_DIRECT 1   // the sets in architectural registers are loaded lane by lane, without staging (gather())
+#endif
+#ifndef PMF_LANE_DIRECT_A
+#define PMF_LANE_DIRECT_A 0   // The AGPR sets loaded straight into their registers as well (inline-asm global_load into "=a" operands: one trip
+                              // to memory per row instead of a pipeline of staged chunks).  NOT adopted, and not safe as it stands: hipcc
+                              // regards an asm output as written when the statement ends, and in the (1, 2, 1) instances -- 512 registers
+                              // in use -- it SPILLS the 200 freshly "loaded" values to scratch right behind the loads, before the data has
+                              // landed (1.6 KB of scratch per lane, wrong tiles).  The staged path writes the same registers with
+                              // v_accvgpr_write from data that is there.
+#endif
+    static constexpr bool DIRECT_A = PMF_LANE_DIRECT && PMF_LANE_DIRECT_A;
+    static constexpr bool STAGED = LL_ > 0 || (LA_ > 0 && !DIRECT_A) || !PMF_LANE_DIRECT;   // some set travels through LDS
+    static constexpr int NBUF = LL_ > 0 ? LL_ * NCH : (!STAGED ? 0 : (SMALL_ ? 1 : 2));  // staging buffers; the chunks of the LDS sets stay in theirs
+    static constexpr bool ALIAS = SMALL_ && NBUF > 0;
     static_assert(!SMALL_ || LL_ == 0, "the shared buffer is free once the gather is done");
     static_assert(KP % NC == 0, "blocks of equal size");
     static constexpr int DB = KP / NC;                    // dimensions per 64-lane block
     static constexpr int CW = (DB + 3) / 4;               // columns: dimension d' of a block lives in lane (d' % CW) + 16 (d' / CW)
     static_assert(CW <= 16 && DB > 2 * CW, "at most 64 dimensions per block, three or four per column");
-    static constexpr int RED_STRIDE = 18 * 8;             // bytes between the 16-double rows of the transpose scratch (conflict-free b128 reads)
+    // bytes between the 16-element rows of the transpose scratch: 18 doubles / 20 floats -- 36 c / 20 c banks for column c are
+    // sixteen different multiples of 4 (mod 64), so the 16 lanes of a ds_read_b128 service group never share a bank
+    static constexpr int RED_STRIDE = sizeof(T) == 8 ? 18 * 8 : 20 * 4;
     static constexpr int RED_BYTES = 4 * 16 * RED_STRIDE; // four 16-lane rows x up to 16 columns
-    static constexpr int AVEC_BYTES = (KP * 8 + 15) / 16 * 16;
+    static constexpr int AVEC_BYTES = (KP * (int)sizeof(T) + 15) / 16 * 16;
     static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + (ALIAS ? 0 : RED_BYTES) + AVEC_BYTES;
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
-    static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * 8 + 16 * ((NW_ * 8 + 15) / 16) : 0;
+    static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) : 0;
     static constexpr int SMEM_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;
     static constexpr bool PIPELINED = true;
     static constexpr bool PARKS = false;
@@ -125,7 +156,19 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static_assert(LV_ >= 1, "at least one set in architectural registers");
 
     T t[LV][KP];                          // the sets in architectural registers
-    unsigned ta[LA > 0 ? LA : 1][KP][2];  // the sets in accumulator registers (AGPR-class values: acc_put / acc_get only)
+    static constexpr int AW = (int)sizeof(T) / 4;   // 32-bit words per element
+    typedef unsigned U4 __attribute__((ext_vector_type(4)));
+    typedef unsigned UE __attribute__((ext_vector_type(sizeof(T) / 4)));
+    UE tae[LA > 0 ? LA : 1][KP];   // the sets in accumulator registers, one AGPR (pair) per element (AGPR-class values: written by
+                                   // acc_put or by a load straight into them, read by acc_get only).  (Quads per 16-byte slot, filled by
+                                   // dwordx4 loads, cost the allocator 1.7 KB of scratch per lane: 128-bit tuples fragment the file.)
+    static constexpr bool PREFETCH = PF_;
+    static_assert(!PF_ || (LV_ == 1 && LA_ == 0 && LL_ == 1 && NW_ == 1 && sizeof(T) == 8 && PMF_LANE_DIRECT), "prefetch: one register set + one LDS set, one wave");
+    typedef unsigned U2 __attribute__((ext_vector_type(2)));
+    U4 pfq[PF_ ? 2 * KS : 1];   // AGPR-class: the next row's slots, [0, KS) of its first 64 nonzeros, [KS, 2 KS) of the rest
+    U2 pfx[PF_ ? 2 : 1];        // AGPR-class: the next row's values
+    U2 pfm[PF_ ? NC : 1];       // AGPR-class: the next row's starting point (its row of the factor being updated)
+    T xt[NC];                   // the current row's starting point, as take_prefetched left it
     T xr[LT];            // x_j of this lane's nonzeros
     unsigned idx_n[LT];  // column indices of the row whose tile is requested next (fetch_meta -> gather)
     T pv[LT], qv[LT];    // cached predictions p_j = F_j . x and q_j = F_j . d (solvers.hpp, cg_row_cached)
@@ -178,6 +221,94 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         nnz = 0;
     }
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
+
+    // ---- prefetch of the next row (PF_; driven by sweep_rows_pf in poismf_hip.hip, ONE call site each: the AGPR-class values
+    // are loop-carried, and every further place that defines them costs a register-to-register copy of all 204) ------------
+    // (plain recursion, here and in acc_load_set: a variable that appears only as an asm operand inside a generic lambda is not
+    // captured by hipcc)
+    template <int S2, int C = 0> __device__ __forceinline__ void acc_load_set(const char* base)
+    {
+        if constexpr (C < KP) {
+            if constexpr (sizeof(T) == 8) asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=a"(tae[S2][C]) : "v"(base), "i"(C * 8));
+            else asm volatile("global_load_dword %0, %1, off offset:%2" : "=a"(tae[S2][C]) : "v"(base), "i"(C * 4));
+            acc_load_set<S2, C + 1>(base);
+        }
+    }
+    template <int S2, int Q = 0> __device__ __forceinline__ void pf_load_set(const char* base)
+    {
+        if constexpr (Q < KS) {
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(pfq[S2 * KS + Q]) : "v"(base), "i"(Q * 16));
+            pf_load_set<S2, Q + 1>(base);
+        }
+    }
+    template <int I> __device__ __forceinline__ void pf_load_m(const T* xp)
+    {
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(pfm[I]) : "v"(xp));
+    }
+    template <int S2> __device__ __forceinline__ void pf_load_x(const T* xp)
+    {
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(pfx[S2]) : "v"(xp));
+    }
+    // The tile of the row whose indices fetch_meta requested last (idx_n), and its values (val, nnz_row of them).  Inline asm:
+    // hipcc has no way to load into AGPRs, and these loads must stay in flight while the solver runs -- the only wait for them is
+    // the explicit one in take_prefetched().  (hipcc's own counted waits can only over-wait because of them: memory returns in order.)
+    // (mrow: the row's current values in the factor being updated -- the solver's starting point)
+    __device__ __forceinline__ void prefetch_issue_row(const T* val, unsigned nnz_row, const T* mrow)
+    {
+        if constexpr (PF_) {
+            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+            static_for<0, 2>([&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                pf_load_set<s2>((const char*)F + (size_t)__umul24(idx_n[s2], rowbytes));
+                const unsigned j = (unsigned)(WAVE * s2 + lane);
+                pf_load_x<s2>(val + (j < nnz_row ? j : 0u));
+            });
+            static_for<0, NC>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                pf_load_m<i>(mrow + (act[i] ? elem[i] : 0));
+            });
+        }
+    }
+    // solve_row: the point the row starts from (engines without prefetch load it here)
+    __device__ __forceinline__ void start_point(const T* mrow, T (&x)[NC]) const
+    {
+        if constexpr (PF_) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) x[i] = xt[i];
+        } else load_vec(mrow, x);
+    }
+    // the prefetched row becomes the current one
+    __device__ __forceinline__ void take_prefetched(unsigned nnz_row)
+    {
+        if constexpr (PF_) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            nnz = nnz_row;
+            static_for<0, KS>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                t[0][q * SN] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[q][1]) << 32) | acc_get(pfq[q][0]));
+                t[0][q * SN + 1] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[q][3]) << 32) | acc_get(pfq[q][2]));
+            });
+            static_for<0, KS>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                constexpr int c = slot_chunk(q);
+                SA v;
+                v.v[0] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[KS + q][1]) << 32) | acc_get(pfq[KS + q][0]));
+                v.v[1] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[KS + q][3]) << 32) | acc_get(pfq[KS + q][2]));
+                *((SA*)(stage + c * STAGE_BYTES) + lane * W + (q - chunk_start(c))) = v;
+            });
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                const T xv = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfx[s2][1]) << 32) | acc_get(pfx[s2][0]));
+                xr[s2] = (unsigned)(WAVE * s2 + lane) < nnz ? xv : (T)0;
+            }
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                const T mv = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfm[i][1]) << 32) | acc_get(pfm[i][0]));
+                xt[i] = act[i] ? mv : (T)0;
+            }
+            wave_lds_fence();
+        }
+    }
 
     // ---- k-vectors: lane <-> dimension -------------------------------------------------------------------------------
     // Several wave-wide sums at once (the solvers' dot products come in groups: theta / beta / |g|^2; g.d / d.d; the three
@@ -294,11 +425,11 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #pragma unroll
             for (int e = 0; e < SN; e++) {
                 if constexpr (S_ < LV) t[S_][q * SN + e] = v.v[e];
-                else {
+                else if constexpr (sizeof(T) == 8) {
                     const unsigned long long b = __builtin_bit_cast(unsigned long long, v.v[e]);
-                    ta[S_ - LV][q * SN + e][0] = acc_put((unsigned)b);
-                    ta[S_ - LV][q * SN + e][1] = acc_put((unsigned)(b >> 32));
-                }
+                    tae[S_ - LV][q * SN + e][0] = acc_put((unsigned)b);
+                    tae[S_ - LV][q * SN + e][1] = acc_put((unsigned)(b >> 32));
+                } else tae[S_ - LV][q * SN + e][0] = acc_put(__builtin_bit_cast(unsigned, v.v[e]));
             }
         });
     }
@@ -325,10 +456,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         // KS loads in flight per lane, no staging, no address arithmetic beyond the row's base.  (64 different rows per
         // instruction: the price is in the texture unit -- 64 tag look-ups per instruction -- which a row pays once; the lines
         // are the same 2-4 per row that a coalesced fetch would bring.)
-#ifndef PMF_LANE_DIRECT
-#define PMF_LANE_DIRECT 1
-#endif
-        constexpr int S0 = PMF_LANE_DIRECT ? LV : 0;   // first set that goes through the staging buffers
+        constexpr int S0 = PMF_LANE_DIRECT ? (DIRECT_A ? LR : LV) : 0;   // first set that goes through the staging buffers
         if constexpr (PMF_LANE_DIRECT) {
             const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
             static_for<0, LV>([&](auto sc) {
@@ -342,7 +470,17 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 });
             });
         }
-        // the other register sets: their chunks pass through the staging buffers, NBUF in flight
+        // Sets in accumulator registers: the same loads, straight into the AGPR quads (inline asm: hipcc cannot address AGPRs;
+        // it does not count these loads either -- the explicit vmcnt(0) below is their wait).  All sets of a row are in flight
+        // together: one trip to memory per row where a staged pipeline of chunks made four.
+        if constexpr (DIRECT_A && LA > 0) {
+            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+            static_for<0, LA>([&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                acc_load_set<s2>((const char*)F + (size_t)__umul24(idx[LV + s2], rowbytes));
+            });
+        }
+        // (without direct loads) the register sets' chunks pass through the staging buffers, NBUF in flight
         constexpr int NWORK = (LR - S0) * NCH;
         constexpr int DEPTH = NBUF < NWORK ? NBUF : NWORK;
         static_for<0, DEPTH>([&](auto wc) {
@@ -365,6 +503,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 dma_chunk<chunk_start(w2 % NCH)>(idx[S0 + w2 / NCH], w % NBUF);
             }
         });
+        if constexpr (DIRECT_A && LA > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (ALIAS) { __builtin_amdgcn_s_waitcnt(0xc07f); wave_lds_fence(); }   // the scratch of the reductions is this buffer
         // LDS sets: their chunks stay in the buffers (set u, chunk c in buffer u NCH + c)
         if constexpr (LL > 0) {
@@ -387,6 +526,13 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     }
 
     // ---- tile access -----------------------------------------------------------------------------------------------------
+    static __device__ __forceinline__ T acc_elem(const UE& w)
+    {
+        if constexpr (sizeof(T) == 8) {
+            const unsigned lo = acc_get(w[0]), hi = acc_get(w[1]);
+            return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
+        } else return __builtin_bit_cast(T, acc_get(w[0]));
+    }
     // slot Q (SN elements) of this lane's nonzero in set S
     template <int S, int Q> __device__ __forceinline__ SA tile_slot() const
     {
@@ -396,10 +542,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             for (int e = 0; e < SN; e++) v.v[e] = t[S][Q * SN + e];
         } else if constexpr (S < LR) {
 #pragma unroll
-            for (int e = 0; e < SN; e++) {
-                const unsigned lo = acc_get(ta[S - LV][Q * SN + e][0]), hi = acc_get(ta[S - LV][Q * SN + e][1]);
-                v.v[e] = __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
-            }
+            for (int e = 0; e < SN; e++) v.v[e] = acc_elem(tae[S - LV][Q * SN + e]);
         } else {
             constexpr int c = slot_chunk(Q);
             v = *((const SA*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + lane * W + (Q - chunk_start(c)));
@@ -410,10 +553,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     template <int S, int C> __device__ __forceinline__ T tile_elem() const
     {
         if constexpr (S < LV) return t[S][C];
-        else if constexpr (S < LR) {
-            const unsigned lo = acc_get(ta[S - LV][C][0]), hi = acc_get(ta[S - LV][C][1]);
-            return __builtin_bit_cast(T, ((unsigned long long)hi << 32) | lo);
-        } else {
+        else if constexpr (S < LR) return acc_elem(tae[S - LV][C]);
+        else {
             constexpr int q = C / SN, c = slot_chunk(q);
             return *((const T*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + (lane * W + (q - chunk_start(c))) * SN + C % SN);
         }
@@ -463,7 +604,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     template <int B> __device__ __forceinline__ T reduce_block(const T (&coef)[LT])
     {
         const int R = lane >> 4, p = lane & 15;
-        unsigned char* wr = red + R * (16 * RED_STRIDE) + p * 8;
+        unsigned char* wr = red + R * (16 * RED_STRIDE) + p * (int)sizeof(T);
         T tl[2][4][LLX];
         load_col<B, 0>(tl[0]);
         static_for<0, CW>([&](auto cc) {
@@ -479,12 +620,12 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         });
         wave_lds_fence();
         const SA* rd = (const SA*)(red + R * (16 * RED_STRIDE) + p * RED_STRIDE);
-        SA v[8];
+        SA v[16 / SN];
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = rd[i];
+        for (int i = 0; i < 16 / SN; i++) v[i] = rd[i];
         T sum = v[0].v[0];
 #pragma unroll
-        for (int i = 1; i < 16; i++) sum += v[i / 2].v[i % 2];
+        for (int i = 1; i < 16; i++) sum += v[i / SN].v[i % SN];
         wave_lds_fence();
         return sum;                                     // lane (R, c): dimension c + CW R (lanes with c >= CW: nothing)
     }
@@ -494,7 +635,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     {
         if constexpr (NW > 1) {
             T* xv = (T*)(xw_base + xw_sel * XW_BYTES);
-            double* xl = (double*)(xw_base + xw_sel * XW_BYTES + NW * WAVE * NC * 8);
+            double* xl = (double*)(xw_base + xw_sel * XW_BYTES + NW * WAVE * NC * (int)sizeof(T));
             xw_sel ^= 1;
             if (vec) {
 #pragma unroll

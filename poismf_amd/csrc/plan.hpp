@@ -169,27 +169,51 @@ inline TeamShape team_shape_for(unsigned max_nnz)
     return { 0, 0 };
 }
 
-// Lane-per-nonzero engine (lane_eval.hpp): doubles with 25 or 50 slots per factor row (k = 49..50, 99..100), CG and TNCG.
-// Lane sets (64 nonzeros each) per wave -- in architectural registers, in accumulator registers, in LDS -- and waves per row
-// for rows of a length class; waves 0 = not a row of this engine.  A function of the class bound alone, so a row's
-// arithmetic does not depend on its shard.
-struct LaneShape { int lv, la, ll, waves; int small; };   // small: 14 KB of LDS per wave, two waves per SIMD
-inline LaneShape lane_shape_for(unsigned cls, int s_load)
-{
-    if (sizeof(real_t) != 8) return { 0, 0, 0, 0, 0 };
-    if (s_load == 25) {          // a set is 100 registers / 25.6 KB of LDS
+// Lane-per-nonzero engine (lane_eval.hpp): factor rows of 25 slots in doubles (k = 49..50; 50 slots, k = 99..100, for the
+// shortest rows) and of 13 slots in floats (k = 49..52).  Lane sets (64 nonzeros each) per wave -- in architectural registers,
+// in accumulator registers, in LDS -- and waves per row for rows of a length class; waves 0 = not a row of this engine.
+// A function of the class bound (and the solver) alone, so a row's arithmetic does not depend on its shard.
+struct LaneShape { int lv, la, ll, waves; int small; };   // small: a few KB of LDS per wave, two waves per SIMD
 #ifndef PMF_LANE_A2
-#define PMF_LANE_A2 0   // rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
+#define PMF_LANE_A2 0   // doubles, rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
                         // (measured, C3 A half, CG fp64: 22.3 ms against 20.0 -- the barrier per evaluation and the second copy of the
                         // solver's chain cost more than the second wave per SIMD hides)
 #endif
+#ifndef PMF_LANE_F32
+#define PMF_LANE_F32 1
+#endif
+inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
+{
+    if (sizeof(real_t) == 8) {
+        if (method == POISMF_PG) return { 0, 0, 0, 0, 0 };
+        if (s_load == 25) {          // a set is 100 registers / 25.6 KB of LDS
+            if (cls <= 64) return { 1, 0, 0, 1, 1 };
+            if (cls <= 128) return PMF_LANE_A2 ? LaneShape{ 1, 0, 0, 2, 1 } : LaneShape{ 1, 0, 1, 1, 0 };
+            if (cls <= 256) return { 1, 2, 1, 1, 0 };
+            if (cls <= 512) return { 1, 2, 1, 2, 0 };
+            if (cls <= 1024) return { 1, 2, 1, 4, 0 };
+        } else if (s_load == 50) {   // a set is 200 registers / 51 KB of LDS
+            if (cls <= 64) return { 1, 0, 0, 1, 0 };
+        }
+    } else if (PMF_LANE_F32 && s_load == 13) {   // floats: a set is 52 registers, every set in architectural registers, two waves per SIMD
+        if (method == POISMF_PG) {
+            // PG does the same work on every pass and the slot layout (reg_eval.hpp) is the cheaper one for single-wave rows; what
+            // the lane layout buys is the long rows: eight waves with NO cross-lane traffic in the dots and one transposing
+            // reduction per wave instead of a butterfly per four-nonzero step
+#ifndef PMF_LANE_PG32
+#define PMF_LANE_PG32 0   // measured, C4 matrix, PG(10) fp32, B half: 9.5 ms against 8.0 ms for reg_eval.hpp's eight-wave kernels: a pass of
+                          // either is ~5 k cycles of barrier / LDS round trips in lockstep, which the cheaper instruction stream does not shorten
+#endif
+            if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };
+            if (PMF_LANE_PG32 && cls > 1024 && cls <= 1536) return { 3, 0, 0, 8, 1 };
+            return { 0, 0, 0, 0, 0 };
+        }
         if (cls <= 64) return { 1, 0, 0, 1, 1 };
-        if (cls <= 128) return PMF_LANE_A2 ? LaneShape{ 1, 0, 0, 2, 1 } : LaneShape{ 1, 0, 1, 1, 0 };
-        if (cls <= 256) return { 1, 2, 1, 1, 0 };
-        if (cls <= 512) return { 1, 2, 1, 2, 0 };
-        if (cls <= 1024) return { 1, 2, 1, 4, 0 };
-    } else if (s_load == 50) {   // a set is 200 registers / 51 KB of LDS
-        if (cls <= 64) return { 1, 0, 0, 1, 0 };
+        if (cls <= 128) return { 2, 0, 0, 1, 1 };
+        if (cls <= 256) return { 2, 0, 0, 2, 1 };
+        if (cls <= 512) return { 2, 0, 0, 4, 1 };
+        if (cls <= 1024) return { 2, 0, 0, 8, 1 };
+        if (cls <= 1536) return { 3, 0, 0, 8, 1 };
     }
     return { 0, 0, 0, 0, 0 };
 }

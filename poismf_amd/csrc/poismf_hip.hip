@@ -43,7 +43,7 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
         if (out_p != nullptr) ev.store_vec(out_p, x);
         return;
     }
-    ev.load_vec(out, x);
+    ev.start_point(out, x);
     ev.n_eval = 0;
 
     // per-row constant term: the k-vector itself, or (w != 1) the reference's Bsum_w row
@@ -193,6 +193,50 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
             if (nnz != 0) ev.begin_row(a.indices + p0, a.values + p0, nnz);
             solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d.lrow), nnz);
         }
+    }
+}
+
+// The row loop of the lane-engine instance that prefetches (lane_eval.hpp, PF_): rows dealt out statically; while row i is being
+// solved, the tile of row i + 1 is in flight into AGPRs and the indices of row i + 2 into registers.  Each of the three steps
+// has ONE call site in the loop.
+template <class EV, class T, int NC, int METHOD>
+__device__ __forceinline__ void sweep_rows_pf(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
+{
+    if (a.gate != nullptr && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    ev.init(a.geom, a.F, smem);
+    T bs[NC];
+    ev.load_vec(a.bsum, bs);
+    const RowDesc* desc = a.desc + a.perm_begin;
+    const unsigned stride = gridDim.x;
+    auto row_of = [&](unsigned t, unsigned& nnz, unsigned long long& p0, unsigned& lrow) {
+        const RowDesc d = desc[t < a.nrows ? t : 0u];   // (past the end: a valid address and no nonzeros -- the loads fetch the zero row)
+        nnz = t < a.nrows ? uniform(d.nnz) : 0u;
+        p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
+        lrow = uniform(d.lrow);
+    };
+    auto mrow_of = [&](unsigned lrow) { return a.M + (size_t)(a.row_offset + lrow) * (size_t)a.geom.k; };
+    unsigned t0 = blockIdx.x;
+    if (t0 >= a.nrows) return;
+    unsigned n0, l0, n1, l1, n2, l2;
+    unsigned long long p0, p1, p2;
+    row_of(t0, n0, p0, l0);
+    ev.fetch_meta(a.indices + p0, n0);
+    ev.prefetch_issue_row(a.values + p0, n0, mrow_of(l0));        // the wave's first row takes the same road as every other one
+    unsigned t1 = t0 + stride;
+    row_of(t1, n1, p1, l1);
+    ev.fetch_meta(a.indices + p1, n1);                            // the second row's indices
+    for (;;) {
+        ev.take_prefetched(n0);                                   // (the one wait: the current row's tile, the next row's indices)
+        // Nothing hipcc counts may be waited for between here and the end of the solve except what is issued BEFORE the prefetch
+        // loads: its counted waits cannot see them, and a wait for anything younger would wait for all of them.
+        const unsigned t2 = t1 + stride;
+        row_of(t2, n2, p2, l2);                                   // (descriptor of the row after next: a short trip, consumed at once)
+        ev.prefetch_issue_row(a.values + p1, n1, mrow_of(l1));    // the next row's tile -> AGPRs, in flight during this row's solve
+        ev.fetch_meta(a.indices + p2, n2);                        // the indices of the row after next -> idx_n (consumed one solve later)
+        solve_row<EV, T, NC, METHOD>(a, ev, bs, l0, n0);
+        if (t1 >= a.nrows) break;
+        t0 = t1; n0 = n1; l0 = l1; p0 = p1;
+        t1 = t2; n1 = n2; l1 = l2; p1 = p2;
     }
 }
 
@@ -444,13 +488,14 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
 
 // Lane-per-nonzero engine (lane_eval.hpp): doubles, 25 or 50 slots per factor row; NW waves per row; one wave per SIMD, or
 // (SMALL: one register set, 14 KB of LDS per wave) two.
-template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL>
+template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF = false>
 __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(SMALL ? 2 : 1, SMALL ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
 {
-    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL>;
+    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
     EV ev;
-    sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
+    if constexpr (PF) sweep_rows_pf<EV, T, EV::NC, METHOD>(a, ev, smem);
+    else sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
 }
 
 namespace {
@@ -553,12 +598,12 @@ template <int M, int S> int launch_team(hipStream_t stream, int method, const Ha
     } else return 1;
 }
 
-// lane-per-nonzero launches (doubles only)
-template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+// lane-per-nonzero launches
+template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false, bool PF = false> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
-    if constexpr (sizeof(real_t) == 8 && tu_has(METHOD) && METHOD != K_PG) {
-        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL>;
-        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL>;
+    if constexpr (tu_has(METHOD)) {
+        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, PF>;
+        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF>;
         // workgroups per CU: one (SMALL: two) waves per SIMD, and the LDS each takes
         const int occ = std::max(1, std::min((SMALL ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
         const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)t_num_cu * (size_t)occ * grid_mult);
@@ -570,18 +615,46 @@ template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false
 template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     const int key = (((lv * 10 + la) * 10 + ll) * 10 + nw) * 10 + small;
-    if (s_load == 25) {
-        switch (key) {
-            case 10011: return launch_lane<METHOD, 25, 1, 0, 0, 1, true>(stream, a, grid_mult);
-            case 10021: return launch_lane<METHOD, 25, 1, 0, 0, 2, true>(stream, a, grid_mult);
-            case 10110: return launch_lane<METHOD, 25, 1, 0, 1, 1>(stream, a, grid_mult);
-            case 12110: return launch_lane<METHOD, 25, 1, 2, 1, 1>(stream, a, grid_mult);
-            case 12120: return launch_lane<METHOD, 25, 1, 2, 1, 2>(stream, a, grid_mult);
-            case 12140: return launch_lane<METHOD, 25, 1, 2, 1, 4>(stream, a, grid_mult);
+    if constexpr (sizeof(real_t) == 8) {
+        if constexpr (METHOD == K_PG) return 1;
+        else if (s_load == 25) {
+            switch (key) {
+                case 10011: return launch_lane<METHOD, 25, 1, 0, 0, 1, true>(stream, a, grid_mult);
+                case 10021: return launch_lane<METHOD, 25, 1, 0, 0, 2, true>(stream, a, grid_mult);
+#ifndef PMF_LANE_PF
+#define PMF_LANE_PF 0   // rows of 65 .. 128 nonzeros: the next row's tile prefetched into AGPRs while this one is solved (lane_eval.hpp, PF_).
+                        // Built, parity-green, and NOT adopted: C3 A half 18.78 ms with it, 18.80 without -- with maxupd = 1 the half
+                        // already runs at the fabric's gather rate (8.8 ms for 40 GB), with maxupd = 5 the waves are waiting on LDS
+                        // round trips and dependent fp64 chains, not on the gather (PMC: SQ_WAIT_ANY 28 % with, 31 % without).  Its asm
+                        // loads into AGPRs are also only safe while the instance has no scratch (lane_eval.hpp, PMF_LANE_DIRECT_A).
+#endif
+                case 10110: return launch_lane<METHOD, 25, 1, 0, 1, 1, false, PMF_LANE_PF != 0>(stream, a, grid_mult);
+                case 12110: return launch_lane<METHOD, 25, 1, 2, 1, 1>(stream, a, grid_mult);
+                case 12120: return launch_lane<METHOD, 25, 1, 2, 1, 2>(stream, a, grid_mult);
+                case 12140: return launch_lane<METHOD, 25, 1, 2, 1, 4>(stream, a, grid_mult);
+            }
+        } else if (s_load == 50) {
+            switch (key) {
+                case 10010: return launch_lane<METHOD, 50, 1, 0, 0, 1>(stream, a, grid_mult);
+            }
         }
-    } else if (s_load == 50) {
-        switch (key) {
-            case 10010: return launch_lane<METHOD, 50, 1, 0, 0, 1>(stream, a, grid_mult);
+    } else {
+        if (s_load == 13) {
+            if constexpr (METHOD == K_PG) {
+                switch (key) {
+                    case 20081: return launch_lane<METHOD, 13, 2, 0, 0, 8, true>(stream, a, grid_mult);
+                    case 30081: return launch_lane<METHOD, 13, 3, 0, 0, 8, true>(stream, a, grid_mult);
+                }
+            } else {
+                switch (key) {
+                    case 10011: return launch_lane<METHOD, 13, 1, 0, 0, 1, true>(stream, a, grid_mult);
+                    case 20011: return launch_lane<METHOD, 13, 2, 0, 0, 1, true>(stream, a, grid_mult);
+                    case 20021: return launch_lane<METHOD, 13, 2, 0, 0, 2, true>(stream, a, grid_mult);
+                    case 20041: return launch_lane<METHOD, 13, 2, 0, 0, 4, true>(stream, a, grid_mult);
+                    case 20081: return launch_lane<METHOD, 13, 2, 0, 0, 8, true>(stream, a, grid_mult);
+                    case 30081: return launch_lane<METHOD, 13, 3, 0, 0, 8, true>(stream, a, grid_mult);
+                }
+            }
         }
     }
     return 1;
@@ -642,6 +715,7 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
     if (o.lane_L > 0) {
+        if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
         if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
         if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
         return 1;

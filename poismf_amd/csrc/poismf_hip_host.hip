@@ -646,9 +646,14 @@ int poismf_hip_session_create_coo(poismf_hip_session** out, int device, void* st
         {
             std::vector<unsigned> h32;
             try { h32.resize(n); } catch (const std::bad_alloc&) { break; }
-            for (size_t i = 0; i < n; i++) h32[i] = (unsigned)row[i];
+            // (an index outside the matrix -- or a negative one reinterpreted as size_t -- would become a gather offset into the
+            // factors: rc 3, which the binding turns into ValueError)
+            bool bad_index = false;
+            for (size_t i = 0; i < n; i++) { bad_index |= (size_t)row[i] >= dimA; h32[i] = (unsigned)row[i]; }
+            if (bad_index) { rc = 3; break; }
             if (hipMemcpy(d_row, h32.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice) != hipSuccess) break;
-            for (size_t i = 0; i < n; i++) h32[i] = (unsigned)col[i];
+            for (size_t i = 0; i < n; i++) { bad_index |= (size_t)col[i] >= dimB; h32[i] = (unsigned)col[i]; }
+            if (bad_index) { rc = 3; break; }
             if (hipMemcpy(d_col, h32.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice) != hipSuccess) break;
         }
         if (hipMemcpy(d_val, val, sizeof(real_t) * n, hipMemcpyHostToDevice) != hipSuccess) break;
@@ -660,7 +665,7 @@ int poismf_hip_session_create_coo(poismf_hip_session** out, int device, void* st
     pmf_free(d_row, s->stream);
     pmf_free(d_col, s->stream);
     pmf_free(d_val, s->stream);
-    if (rc) { poismf_hip_session_destroy(s); return 1; }
+    if (rc) { poismf_hip_session_destroy(s); return rc; }
     *out = s;
     return 0;
 }
@@ -938,8 +943,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // lane-per-nonzero engine (lane_eval.hpp): doubles with 25 / 50 slots per factor row, CG and TNCG; 24-bit row ids and
     // row strides, 32-bit byte offsets into the factor (as the register engine)
     static const bool no_lane = getenv("POISMF_HIP_NO_LANE") != nullptr;  // testing knob
-    const bool lane_ok = !no_lane && sizeof(real_t) == 8 && (p->method == POISMF_CG || p->method == POISMF_TNCG) &&
-                         dimF < ((size_t)1 << 24) && ldF * sizeof(real_t) < ((size_t)1 << 24) &&
+    const bool lane_ok = !no_lane && !single_pass && dimF < ((size_t)1 << 24) && ldF * sizeof(real_t) < ((size_t)1 << 24) &&
                          (dimF + 1) * ldF * sizeof(real_t) + 16 < ((size_t)1 << 32);
     static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
@@ -951,7 +955,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         TileGeom g = plan_geom(s->k, b.cls, single_pass, p->method == POISMF_CG && p->limit_step);
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
         if (lane_ok) {
-            const LaneShape ls = lane_shape_for(b.cls, g.s_load);
+            const LaneShape ls = lane_shape_for(b.cls, g.s_load, p->method);
             if (ls.waves > 0) {
                 if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small &&
                     launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)

@@ -168,6 +168,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     static constexpr int NW = NW_;
     static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
     static constexpr bool FUSED_SUMS = false;     // (lane_eval.hpp reduces the solvers' groups of dot products together)
+    static constexpr bool PREFETCH = false;       // (lane_eval.hpp can request the next row's tile while this one is solved)
     static constexpr int KP = G * NS * SN;        // elements of a (padded) k-vector in the cross-wave scratch
     static constexpr int M = M_;
     // one set of cross-wave scratch: NW partial k-vectors and NW scalars (teams: NW x TEAM_SC scalars)
@@ -286,6 +287,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     // k-vector in global memory <-> registers, one 16-byte access per slot (the vectors this engine touches -- factor
     // rows, the column-sum vector -- all have >= 16 bytes of slack behind them, so the last, partly filled slot may be
     // read whole; it is written element by element)
+    __device__ __forceinline__ void start_point(const T* mrow, T (&x)[NC]) const { load_vec(mrow, x); }   // (lane_eval.hpp may have it prefetched)
     __device__ __forceinline__ void load_vec(const T* p, T (&x)[NC]) const
     {
 #pragma unroll

@@ -157,6 +157,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     static constexpr int NS = NC / SN;
     static constexpr bool PIPELINED = false;  // sweep_rows: no cross-row prefetch (the LDS tile has one set of index buffers)
     static constexpr bool FUSED_SUMS = false;     // (lane_eval.hpp reduces the solvers' groups of dot products together)
+    static constexpr bool PREFETCH = false;       // (lane_eval.hpp can request the next row's tile while this one is solved)
     static constexpr bool MAY_CACHE = true;   // cached CG line search where the launch geometry has room for it (pq_cap)
     static constexpr int PRE = PMF_PRE;       // 16-byte slots per lane a prefetched chunk may take (19: 1216 slots = 19 KiB)
     static_assert(NC % SN == 0, "a lane holds whole 16-byte slots");
@@ -278,6 +279,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     __device__ __forceinline__ T nrm2(const T (&u)[NC]) const { return (T)d_sqrt((double)dot(u, u)); }
 
     // k-vector in global memory -> registers (every copy loads it; inactive elements read as 0)
+    __device__ __forceinline__ void start_point(const T* mrow, T (&x)[NC]) const { load_vec(mrow, x); }   // (lane_eval.hpp may have it prefetched)
     __device__ __forceinline__ void load_vec(const T* p, T (&x)[NC]) const
     {
 #pragma unroll

@@ -144,9 +144,10 @@ def _row_lengths(trip, which):
     return np.bincount(major, minlength=trip.shape[0] if which else trip.shape[1])
 
 
-def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True):
+def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True, warm_sweeps=0):
     """Runs one B half and one A half on the full matrix and checks SAMPLE rows of each against the oracle.  Returns the
-    observed maxima so that the caller's tolerances are measured numbers."""
+    observed maxima so that the caller's tolerances are measured numbers.  warm_sweeps > 0: that many full sweeps run first, so
+    that the checked halves are steady-state ones (rows near their optimum: fewer evaluations, other branches of the solvers)."""
     dimA, dimB = trip.shape
     A0, B0 = harness.initialize_matrices(dimA, dimB, k, use_float, 1)
     l2, mu, _ = harness.auto_defaults(method, k)
@@ -163,6 +164,11 @@ def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True):
         cnst_div = s.cnst_div(l2, step)
         rng = np.random.default_rng(7)
         prevA, prevB = A0, B0
+        for _ in range(warm_sweeps):
+            step = s.sweep(p, step)
+            cnst_div = s.cnst_div(l2, step)
+        if warm_sweeps:
+            prevA, prevB = s.get_factors()
         for which in (0, 1):
             if which == 1 and method == "pg":
                 step = s.real(step * 0.5)
@@ -203,6 +209,18 @@ def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True):
                     fr = _row_objectives(Ms, F, sd, si, sptr, bs, l2o)
                     stats[f"obj{which}{tag}"] = abs(fo.sum() - fr.sum()) / abs(fr.sum())
                     stats[f"objrow{which}{tag}"] = float(np.max(np.abs(fo - fr) / np.maximum(np.abs(fr), 1e-300)))
+                    stats[f"rows_close{which}{tag}"] = float(np.mean(np.abs(fo - fr) <= 1e-4 * np.abs(fr)))
+                    if method == "tncg" and not tag:
+                        # The reference against ITSELF on the same rows: the plain-loop build of the restatement against the build that
+                        # sums through the reference's BLAS (bit-identical to the compiled reference) -- two summation orders of one
+                        # algorithm.  From a cold start (reuse_prev off: every coordinate at 1e-3) or near a row's optimum TNC's line
+                        # search fails or succeeds on rounding, in the reference too; this is the yardstick for such rows.
+                        plain = bindings.Oracle(use_float)
+                        Mp_ = np.ascontiguousarray(Mprev[rows])
+                        plain.tncg_iteration(Mp_, F, reuse_prev, sd, sptr, si, bs, l2, 1.0, maxupd, False)
+                        fp_ = _row_objectives(Mp_, F, sd, si, sptr, bs, l2o)
+                        stats[f"self{which}"] = abs(fp_.sum() - fr.sum()) / abs(fr.sum())
+                        stats[f"self_rows_close{which}"] = float(np.mean(np.abs(fp_ - fr) <= 1e-4 * np.abs(fr)))
                     if os.environ.get("POISMF_TEST_VERBOSE") and not tag:
                         lens = np.diff(sptr.astype(np.int64))
                         worst = np.argsort(-np.abs(fo - fr) / np.maximum(np.abs(fr), 1e-300))[:5]
@@ -274,8 +292,21 @@ def c5_trip():
     return synth.Triplets(c.row.astype(np.int64), c.col.astype(np.int64), np.asarray(c.data, np.float64), c.shape)
 
 
-def test_c5_tncg_fp64_fullsize(c5_trip):
+@pytest.mark.parametrize("reuse_prev,warm_sweeps", [(True, 0), (False, 0), (True, 2)])
+def test_c5_tncg_fp64_fullsize(c5_trip, reuse_prev, warm_sweeps):
     """BASELINE config C5: Last.FM-shaped 358 858 x 160 112, ~17 M nnz, power-law item degrees (rows of > 1e5
-    nonzeros: the long-row path), k = 100, tncg fp64, maxupd = 15 k"""
-    st = _fullsize_halves(c5_trip, 100, "tncg", False, None, reuse_prev=True)
-    assert max(st["obj0"], st["obj1"]) <= 1e-5          # SURVEY 8c: TNCG fp64 objective (measured 2.8e-8 / 2.0e-10)
+    nonzeros: the long-row path), k = 100, tncg fp64, maxupd = 15 k.  Both `reuse_prev` settings (ref:
+    src/poismf.c:379-381: rows restart at 1e-3 when it is off), and -- with reuse_prev -- the THIRD sweep as well as the first
+    (steady state: rows start near their optimum, TNC stops on other criteria)."""
+    st = _fullsize_halves(c5_trip, 100, "tncg", False, None, reuse_prev=reuse_prev, warm_sweeps=warm_sweeps)
+    if reuse_prev and not warm_sweeps:
+        assert max(st["obj0"], st["obj1"]) <= 1e-5      # SURVEY 8c: TNCG fp64 objective (measured 4.7e-9 / 2.0e-10)
+    else:
+        # Cold starts (every coordinate at 1e-3) and third sweeps: some rows' line searches fail or succeed on rounding -- in the
+        # reference as well: its plain-loop and its BLAS build end up to 20 % apart on single rows of this sample (measured: the
+        # slot engine of round 2 and the lane engine of round 3 both show the same kind of rows, 3.7e-8 .. 1.1e-2 in the sample's
+        # total).  The yardstick is the reference against itself on the SAME rows: the GPU must be as close to the compiled
+        # reference's flavour as the other flavour is (x3), and agree with it on as many rows (-3 %).
+        for w in (0, 1):
+            assert st[f"obj{w}"] <= max(5e-5, 3.0 * st[f"self{w}"]), (w, st[f"obj{w}"], st[f"self{w}"])
+            assert st[f"rows_close{w}"] >= min(0.97, st[f"self_rows_close{w}"] - 0.03), (w, st[f"rows_close{w}"], st[f"self_rows_close{w}"])

@@ -540,3 +540,15 @@ def test_session_resident_predict_and_topn(prec):
     with pytest.raises(ValueError):
         s.topn(0, 5, np.array([1, 2], np.uint64), np.array([3], np.uint64))      # include and exclude together
     s.close()
+
+
+def test_coo_session_rejects_indices_outside_the_matrix():
+    """round-2 advisor finding: poismf_hip_session_create_coo narrowed its indices unchecked; an index outside the matrix (or a
+    negative one reinterpreted as size_t) would reach the row kernels as a gather offset"""
+    from poismf_amd import synth
+    good = synth.Triplets(np.array([0, 1, 2], np.int64), np.array([0, 1, 2], np.int64), np.ones(3), (3, 3))
+    api.Session.from_coo(good, 5, False).close()
+    for bad_row, bad_col in (([0, 1, 3], [0, 1, 2]), ([0, 1, 2], [0, 7, 2]), ([0, -1, 2], [0, 1, 2])):
+        t = synth.Triplets(np.array(bad_row, np.int64), np.array(bad_col, np.int64), np.ones(3), (3, 3))
+        with pytest.raises(ValueError):
+            api.Session.from_coo(t, 5, False)
