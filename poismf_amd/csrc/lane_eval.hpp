@@ -109,12 +109,18 @@ __device__ __forceinline__ unsigned acc_get(unsigned a)
 // the next row is then 200 v_accvgpr_reads and 25 ds_write_b128 instead of a trip to memory.  A row's gather runs at the
 // fabric's gather ceiling (C3: 40 GB per half = 6.7 ms at 6 TB/s) and, at one wave per SIMD, nothing else overlapped it: it
 // was a third of the half.  (One architectural set + one LDS set, one wave per row: what rows of 65 .. 128 nonzeros take.)
-template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false> struct LaneEval {
+// LP_: a further, PARTIAL set of LP_ (16) nonzeros per wave in LDS (lanes >= LP_ of that set alias lanes < LP_ with a zero
+// coefficient), and the transposing reduction's scratch used in two halves -- what makes rows of 1025 .. 1088 nonzeros fit ONE
+// CU: 4 waves x (64 + 128 + 64 + 16) nonzeros, 155 KB of LDS.
+template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0> struct LaneEval {
     using SA = typename Slot<T>::A;
     static constexpr int SN = Slot<T>::N;                 // elements per 16-byte slot
     static constexpr int KP = KS * SN;                    // elements of a factor row, padded to whole slots
     static constexpr int NC = (KP + WAVE - 1) / WAVE;     // elements of a k-vector per lane
-    static constexpr int LV = LV_, LA = LA_, LL = LL_, LR = LV_ + LA_, LT = LV_ + LA_ + LL_;   // sets: VGPR, AGPR, LDS
+    static constexpr int LP = LP_;                                                  // nonzeros of the partial LDS set (0: none)
+    static constexpr int LLT = LL_ + (LP_ > 0 ? 1 : 0);                              // sets read from LDS (the partial one last)
+    static constexpr int LV = LV_, LA = LA_, LL = LL_, LR = LV_ + LA_, LT = LV_ + LA_ + LLT;   // sets: VGPR, AGPR, LDS
+    static_assert(LP_ == 0 || (LL_ > 0 && (LP_ & (LP_ - 1)) == 0 && LP_ < WAVE), "a partial set comes after a full LDS set");
     static constexpr int L = LT, NW = NW_, M = 1;
     static constexpr int W = KS < 13 ? KS : 13;           // slots per staged chunk (row stride of the LDS image: 13 slots = 52 banks, conflict-free b128 reads)
     static constexpr int NCH = (KS + W - 1) / W;          // chunks per factor row; chunk c starts at slot min(c W, KS - W)
@@ -142,9 +148,12 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // bytes between the 16-element rows of the transpose scratch: 18 doubles / 20 floats -- 36 c / 20 c banks for column c are
     // sixteen different multiples of 4 (mod 64), so the 16 lanes of a ds_read_b128 service group never share a bank
     static constexpr int RED_STRIDE = sizeof(T) == 8 ? 18 * 8 : 20 * 4;
-    static constexpr int RED_BYTES = 4 * 16 * RED_STRIDE; // four 16-lane rows x up to 16 columns
+    static constexpr int RED_PH = LP_ > 0 ? 2 : 1;        // the columns pass through the scratch in this many groups
+    static constexpr int RED_COLS = RED_PH == 1 ? 16 : (CW + 1) / 2;
+    static constexpr int RED_BYTES = 4 * RED_COLS * RED_STRIDE; // four 16-lane rows x the columns of a group
+    static constexpr int PART_BYTES = LP_ * W * 16;       // one chunk of the partial set
     static constexpr int AVEC_BYTES = (KP * (int)sizeof(T) + 15) / 16 * 16;
-    static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + (ALIAS ? 0 : RED_BYTES) + AVEC_BYTES;
+    static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES) + AVEC_BYTES;
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
     static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) : 0;
     static constexpr int SMEM_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;
@@ -185,6 +194,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     unsigned nnz;        // nonzeros of the row held by THIS wave
     unsigned n_eval;
     unsigned char* stage;   // this wave's NBUF staging buffers
+    unsigned char* part;    // this wave's partial LDS set (LP_ > 0): NCH chunk images of LP_ rows
     unsigned char* red;     // this wave's transpose scratch
     SA* avec;               // this wave's copy of the current point, as slots
     unsigned char* xw_base; // NW > 1: cross-wave scratch
@@ -208,8 +218,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         k = geo.k; ldF = geo.ldF; zero_row = geo.zero_row;
         unsigned char* p = smem + (size_t)wid * WAVE_BYTES;
         stage = p;
-        red = ALIAS ? p : p + NBUF * STAGE_BYTES;
-        avec = (SA*)(p + NBUF * STAGE_BYTES + (ALIAS ? 0 : RED_BYTES));
+        part = p + NBUF * STAGE_BYTES;
+        red = ALIAS ? p : p + NBUF * STAGE_BYTES + NCH * PART_BYTES;
+        avec = (SA*)(p + NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES));
         xw_base = smem + (size_t)NW * WAVE_BYTES;
         xw_sel = 0;
         ticket_word = (unsigned*)(smem + (size_t)NW * WAVE_BYTES + 2 * XW_BYTES);
@@ -511,8 +522,36 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 constexpr int w = decltype(wc)::value;
                 dma_chunk<chunk_start(w % NCH)>(idx[LR + w / NCH], w);
             });
+            if constexpr (LP > 0) {
+                static_for<0, NCH>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    dma_chunk_part<chunk_start(c)>(idx[LT - 1], c);
+                });
+            }
             wait_dma<0>();
         }
+    }
+    // the same for the partial set: LP rows, ceil(LP W / 64) instructions, the lanes past the image masked off
+    template <int Q0> __device__ __forceinline__ void dma_chunk_part(unsigned idx, int c)
+    {
+        const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+        unsigned j4 = (unsigned)(lane / W) * 4u;
+        unsigned q16 = (unsigned)(lane % W) * 16u;
+        unsigned char* dst = part + c * PART_BYTES;
+        constexpr int NI = (LP * W + WAVE - 1) / WAVE;
+        static_for<0, NI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const unsigned col = (unsigned)__builtin_amdgcn_ds_bpermute((int)j4, (int)idx);
+            const unsigned off = __umul24(col, rowbytes) + q16 + (unsigned)(Q0 * 16);
+            if (j4 < (unsigned)(LP * 4))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)F + (size_t)off),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            j4 += (unsigned)(WAVE / W) * 4u;
+            q16 += (unsigned)(WAVE % W) * 16u;
+            const bool wrap = q16 >= (unsigned)(W * 16);
+            q16 = wrap ? q16 - (unsigned)(W * 16) : q16;
+            j4 = wrap ? j4 + 4u : j4;
+        });
     }
 
     __device__ __forceinline__ void set_point(const T (&x)[NC])
@@ -545,7 +584,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             for (int e = 0; e < SN; e++) v.v[e] = acc_elem(tae[S - LV][Q * SN + e]);
         } else {
             constexpr int c = slot_chunk(Q);
-            v = *((const SA*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + lane * W + (Q - chunk_start(c)));
+            if constexpr (S - LR < LL) v = *((const SA*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + lane * W + (Q - chunk_start(c)));
+            else v = *((const SA*)(part + c * PART_BYTES) + (lane & (LP - 1)) * W + (Q - chunk_start(c)));   // (lanes >= LP: some row's finite data, coefficient 0)
         }
         return v;
     }
@@ -556,7 +596,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         else if constexpr (S < LR) return acc_elem(tae[S - LV][C]);
         else {
             constexpr int q = C / SN, c = slot_chunk(q);
-            return *((const T*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + (lane * W + (q - chunk_start(c))) * SN + C % SN);
+            if constexpr (S - LR < LL) return *((const T*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + (lane * W + (q - chunk_start(c))) * SN + C % SN);
+            else return *((const T*)(part + c * PART_BYTES) + ((lane & (LP - 1)) * W + (q - chunk_start(c))) * SN + C % SN);
         }
     }
 
@@ -564,14 +605,14 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // The elements of the LDS sets that column COL needs (dimensions COL + CW r, r < 4, of block B), requested one column
     // ahead of their use; sched_barriers keep the compiler from requesting the whole tile at once (left alone it puts all 50
     // reads of a pass in flight and parks their 200 destination registers in AGPRs).
-    static constexpr int LLX = LL > 0 ? LL : 1;
+    static constexpr int LLX = LLT > 0 ? LLT : 1;
     template <int B, int COL> __device__ __forceinline__ void load_col(T (&tl)[4][LLX]) const
     {
         static_for<0, 4>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             constexpr int d = COL + CW * r;
             if constexpr (d < DB) {
-                static_for<0, LL>([&](auto uc) {
+                static_for<0, LLT>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
                     tl[r][u] = tile_elem<LR + u, DB * B + d>();
                 });
@@ -587,7 +628,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             constexpr int s = decltype(sc)::value;
             v = fma_t(coef[s], tile_elem<s, C>(), v);
         });
-        static_for<0, LL>([&](auto uc) {
+        static_for<0, LLT>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             v = fma_t(coef[LR + u], tl[R][u], v);
         });
@@ -604,8 +645,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     template <int B> __device__ __forceinline__ T reduce_block(const T (&coef)[LT])
     {
         const int R = lane >> 4, p = lane & 15;
-        unsigned char* wr = red + R * (16 * RED_STRIDE) + p * (int)sizeof(T);
+        unsigned char* wr = red + R * (RED_COLS * RED_STRIDE) + p * (int)sizeof(T);
         T tl[2][4][LLX];
+        T result = (T)0;
         load_col<B, 0>(tl[0]);
         static_for<0, CW>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
@@ -615,19 +657,25 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             T o;
             if constexpr (c + CW < DB) o = swap_fold<16>(x, level_a<B, c, 1>(coef, tl[c & 1]));   // rows 1 | 3
             else o = swap_fold<16>(x, x);
-            *(T*)(wr + c * RED_STRIDE) = o;             // lane (R, p): dimension c + CW R, summed over the four lanes (., p)
+            *(T*)(wr + (c % RED_COLS) * RED_STRIDE) = o;             // lane (R, p): dimension c + CW R, summed over the four lanes (., p)
             pin_here();
+            // the last column of a group: lane (R, c') adds up column c' of the group over the 16 lanes of its row
+            if constexpr ((c + 1) % RED_COLS == 0 || c + 1 == CW) {
+                constexpr int c_first = c / RED_COLS * RED_COLS;
+                wave_lds_fence();
+                const int pc = p >= c_first ? p - c_first : 0;
+                const SA* rd = (const SA*)(red + R * (RED_COLS * RED_STRIDE) + (pc < RED_COLS ? pc : 0) * RED_STRIDE);
+                SA v[16 / SN];
+#pragma unroll
+                for (int i = 0; i < 16 / SN; i++) v[i] = rd[i];
+                T sum = v[0].v[0];
+#pragma unroll
+                for (int i = 1; i < 16; i++) sum += v[i / SN].v[i % SN];
+                result = (p >= c_first && p <= c) ? sum : result;
+                wave_lds_fence();
+            }
         });
-        wave_lds_fence();
-        const SA* rd = (const SA*)(red + R * (16 * RED_STRIDE) + p * RED_STRIDE);
-        SA v[16 / SN];
-#pragma unroll
-        for (int i = 0; i < 16 / SN; i++) v[i] = rd[i];
-        T sum = v[0].v[0];
-#pragma unroll
-        for (int i = 1; i < 16; i++) sum += v[i / SN].v[i % SN];
-        wave_lds_fence();
-        return sum;                                     // lane (R, c): dimension c + CW R (lanes with c >= CW: nothing)
+        return result;                                  // lane (R, c): dimension c + CW R (lanes with c >= CW: nothing)
     }
 
     // NW > 1: add up the NW waves' results (fixed order; every wave ends with the same bits)
@@ -686,7 +734,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                     constexpr int i = decltype(ic)::value, q = g * GQ + i;
                     if constexpr (q < KS) {
                         a_[i] = avec[q];                    // the same address in every lane
-                        static_for<0, LL>([&](auto uc) {
+                        static_for<0, LLT>([&](auto uc) {
                             constexpr int u = decltype(uc)::value;
                             t_[u][i] = tile_slot<LR + u, q>();
                         });

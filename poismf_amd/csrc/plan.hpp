@@ -173,7 +173,7 @@ inline TeamShape team_shape_for(unsigned max_nnz)
 // shortest rows) and of 13 slots in floats (k = 49..52).  Lane sets (64 nonzeros each) per wave -- in architectural registers,
 // in accumulator registers, in LDS -- and waves per row for rows of a length class; waves 0 = not a row of this engine.
 // A function of the class bound (and the solver) alone, so a row's arithmetic does not depend on its shard.
-struct LaneShape { int lv, la, ll, waves; int small; };   // small: a few KB of LDS per wave, two waves per SIMD
+struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; };   // small: a few KB of LDS per wave, two waves per SIMD; lp: nonzeros of a partial LDS set
 #ifndef PMF_LANE_A2
 #define PMF_LANE_A2 0   // doubles, rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
                         // (measured, C3 A half, CG fp64: 22.3 ms against 20.0 -- the barrier per evaluation and the second copy of the
@@ -192,6 +192,7 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
             if (cls <= 256) return { 1, 2, 1, 1, 0 };
             if (cls <= 512) return { 1, 2, 1, 2, 0 };
             if (cls <= 1024) return { 1, 2, 1, 4, 0 };
+            if (cls <= 1088) return { 1, 2, 1, 4, 0, 16 };   // 4 x (64 + 128 + 64 + 16) nonzeros: C3's item rows (Poisson(1000)) end here but for 0.3 %
         } else if (s_load == 50) {   // a set is 200 registers / 51 KB of LDS
             if (cls <= 64) return { 1, 0, 0, 1, 0 };
         }
@@ -236,6 +237,7 @@ int slots_per_lane(size_t k)
 struct OneLaunch {
     int reg_S, nw, s_load, spl;   // register-engine steps (0: LDS engine), waves per row, slots per factor row, slots per lane
     int team;                     // > 1: CUs per row (team launch)
+    int lane_LP;                  // lane engine: nonzeros of the partial LDS set per wave
     int lane_small;               // lane engine: the two-waves-per-SIMD flavour (lane_eval.hpp, SMALL_)
     int lane_L, lane_A, lane_LL;  // lane_L > 0: lane-per-nonzero engine with this many lane sets per wave in VGPRs, AGPRs, LDS (nw waves per row)
     bool generic_only;

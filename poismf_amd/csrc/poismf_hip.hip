@@ -488,10 +488,10 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
 
 // Lane-per-nonzero engine (lane_eval.hpp): doubles, 25 or 50 slots per factor row; NW waves per row; one wave per SIMD, or
 // (SMALL: one register set, 14 KB of LDS per wave) two.
-template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF = false>
+template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF = false, int LP = 0>
 __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(SMALL ? 2 : 1, SMALL ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
 {
-    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF>;
+    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
     EV ev;
     if constexpr (PF) sweep_rows_pf<EV, T, EV::NC, METHOD>(a, ev, smem);
@@ -599,11 +599,11 @@ template <int M, int S> int launch_team(hipStream_t stream, int method, const Ha
 }
 
 // lane-per-nonzero launches
-template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false, bool PF = false> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false, bool PF = false, int LP = 0> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (tu_has(METHOD)) {
-        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, PF>;
-        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF>;
+        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, PF, LP>;
+        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>;
         // workgroups per CU: one (SMALL: two) waves per SIMD, and the LDS each takes
         const int occ = std::max(1, std::min((SMALL ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
         const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)t_num_cu * (size_t)occ * grid_mult);
@@ -612,9 +612,9 @@ template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false
         return 0;
     } else return 1;
 }
-template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, int lp, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
-    const int key = (((lv * 10 + la) * 10 + ll) * 10 + nw) * 10 + small;
+    const int key = (((lv * 10 + la) * 10 + ll) * 10 + nw) * 10 + small + (lp > 0 ? 100000 : 0);
     if constexpr (sizeof(real_t) == 8) {
         if constexpr (METHOD == K_PG) return 1;
         else if (s_load == 25) {
@@ -632,6 +632,7 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
                 case 12110: return launch_lane<METHOD, 25, 1, 2, 1, 1>(stream, a, grid_mult);
                 case 12120: return launch_lane<METHOD, 25, 1, 2, 1, 2>(stream, a, grid_mult);
                 case 12140: return launch_lane<METHOD, 25, 1, 2, 1, 4>(stream, a, grid_mult);
+                case 112140: return launch_lane<METHOD, 25, 1, 2, 1, 4, false, false, 16>(stream, a, grid_mult);
             }
         } else if (s_load == 50) {
             switch (key) {
@@ -715,9 +716,9 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
     if (o.lane_L > 0) {
-        if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
-        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
-        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, a, o.grid_mult);
+        if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
+        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
+        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
         return 1;
     }
 #ifdef PMF_LANE_ONLY   // development: compile the lane-per-nonzero kernels alone (seconds instead of minutes)
