@@ -7,6 +7,10 @@
 // every run (scripts/probes/probe_det.py shows it as B == 0 after a CG half-sweep).  The set-up is dominated by stream
 // creation anyway (7.5 ms per stream, scripts/probes/h2d_probe.hip), which the session avoids by recycling its streams.
 // POISMF_HIP_ASYNC_ALLOC=1 switches the stream-ordered allocator back on (development only).
+// Round 3: large arrays (16 MB and up) are the exception to "synchronous copies" -- they travel through PINNED chunks with
+// hipMemcpyAsync in stream order (second half of this file); the memory itself stays plain hipMalloc, and what misbehaved
+// above was the pool allocator together with asynchronous copies from PAGEABLE memory, neither of which this path uses
+// (tests/test_gpu_upload.py: same bits with and without it, several sessions per process).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -89,12 +93,18 @@ inline int pmf_host_threads()
     }();
     return n;
 }
+// arrays below 16 MB are not worth the threads (testing knobs: POISMF_HIP_NO_STAGED_UPLOAD, POISMF_HIP_STAGED_MIN_BYTES)
+inline bool pmf_staged_wanted(size_t bytes)
+{
+    static const bool off = getenv("POISMF_HIP_NO_STAGED_UPLOAD") != nullptr;
+    static const size_t least = getenv("POISMF_HIP_STAGED_MIN_BYTES") ? (size_t)atoll(getenv("POISMF_HIP_STAGED_MIN_BYTES")) : ((size_t)16 << 20);
+    return !off && bytes >= least && bytes > 0;
+}
 // dst[0 .. n) items of `item` bytes each; fill(pinned, first_item, count) writes count items.  Returns hipErrorNotReady when the
 // staged path is not available (pool busy / no pinned memory / small array): the caller then uses pmf_upload.
 template <class Fill> inline hipError_t pmf_upload_staged(void* dst, size_t n, size_t item, int device, hipStream_t stream, Fill&& fill)
 {
-    static const bool off = getenv("POISMF_HIP_NO_STAGED_UPLOAD") != nullptr;   // testing knob
-    if (off || n * item < ((size_t)16 << 20)) return hipErrorNotReady;
+    if (!pmf_staged_wanted(n * item)) return hipErrorNotReady;
     PmfPinPool& pool = pmf_pin_pool();
     std::unique_lock<std::mutex> lk(pool.busy, std::try_to_lock);
     if (!lk.owns_lock() || !pool.prepare(device)) return hipErrorNotReady;
@@ -129,8 +139,7 @@ template <class Fill> inline hipError_t pmf_upload_staged(void* dst, size_t n, s
 // array while the next chunk of each is in flight.  take(pinned, first_item, count) consumes count items.
 template <class Take> inline hipError_t pmf_download_staged(const void* src, size_t n, size_t item, int device, hipStream_t stream, Take&& take)
 {
-    static const bool off = getenv("POISMF_HIP_NO_STAGED_UPLOAD") != nullptr;
-    if (off || n * item < ((size_t)16 << 20)) return hipErrorNotReady;
+    if (!pmf_staged_wanted(n * item)) return hipErrorNotReady;
     PmfPinPool& pool = pmf_pin_pool();
     std::unique_lock<std::mutex> lk(pool.busy, std::try_to_lock);
     if (!lk.owns_lock() || !pool.prepare(device)) return hipErrorNotReady;

@@ -1,14 +1,14 @@
 #!/bin/bash
-# usage: scripts/install_profiles.sh <tag> [round dir, default r02]: copy what scripts/profile_round.sh left in
+# usage: scripts/install_profiles.sh <tag> [round dir, default r03]: copy what scripts/profile_round.sh left in
 # gpurun_out/<tag>/ into profiles/<round>/ (tracked) and refresh profiles/hbm_traffic.json
 set -e
 cd "$(dirname "$0")/.."
-SRC=gpurun_out/$1; DST=profiles/${2:-r02}
+SRC=gpurun_out/$1; DST=profiles/${2:-r03}
 KEEP=$(mktemp -d); [ -d $DST/run_config ] && cp -r $DST/run_config $KEEP/   # (scripts/run_config.py's records live there too)
 rm -rf $DST; mkdir -p $DST/pmc
 [ -d $KEEP/run_config ] && cp -r $KEEP/run_config $DST/; rm -rf $KEEP
 cp $SRC/bench_line.json $DST/bench_line.json
-for n in pg10 pg1 cg64; do
+for n in pg10 pg1 cg64 cg32 tncg32; do
   cp $SRC/kt_$n/kt_kernel_stats.csv $DST/kt_${n}_kernel_stats.csv
   cp $SRC/kt_${n}_bench_line.json $DST/
   for c in f w t sq; do cp $(find $SRC/pmc_${c}_$n -name summary.txt | head -1) $DST/pmc/pmc_${c}_${n}.summary.txt; done
@@ -16,7 +16,7 @@ done
 cp $SRC/hbm_traffic.json profiles/hbm_traffic.json
 python3 - <<PY
 import csv, json
-for tag, n in (("kt_pg10", 12), ("kt_pg1", 12), ("kt_cg64", 6)):
+for tag, n in (("kt_pg10", 12), ("kt_pg1", 12), ("kt_cg64", 6), ("kt_cg32", 6), ("kt_tncg32", 6)):
     rows = list(csv.DictReader(open(f"$DST/{tag}_kernel_stats.csv")))
     tot = sum(float(r["TotalDurationNs"]) for r in rows if "half_sweep" in r["Name"])
     d = json.loads(open(f"$DST/{tag}_bench_line.json").read())

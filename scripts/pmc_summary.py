@@ -11,7 +11,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(path)):
     if int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) < min_grid:
         continue
-    name = r["Kernel_Name"].split("(")[0][-60:]
+    name = r["Kernel_Name"].split("(")[0][-110:]   # (long enough for half_sweep_lane_kernel<...> with its ten arguments)
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in acc.items():
     print(name)

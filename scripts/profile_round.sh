@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, through gpurun):  scripts/profile_round.sh <tag>
 # Produces gpurun_out/<tag>/: the default bench line, rocprofv3 --kernel-trace --stats of the workloads behind it (PG fp32
-# with maxupd 10 and 1, CG fp64, all on the 1M x 100K / 1e8-nnz matrix) and PMC passes (FETCH_SIZE and WRITE_SIZE separately,
+# with maxupd 10 and 1, CG fp64, CG fp32, TNCG fp32, all on the 1M x 100K / 1e8-nnz matrix) and PMC passes (FETCH_SIZE and WRITE_SIZE separately,
 # TCC hit / miss, SQ issue / wait counters) of the same commands.  scripts/install_profiles.sh copies the summaries to profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1
@@ -24,6 +24,8 @@ run() {   # name, sweeps flags..., bench flags
 run pg10 --steps 5 --warmup 1
 run pg1 --steps 5 --warmup 1 --maxupd 1
 run cg64 --steps 2 --warmup 1 --method cg --fp64
+run cg32 --steps 2 --warmup 1 --method cg
+run tncg32 --steps 2 --warmup 1 --method tncg
 for f in $(find $OUT -name "*counter_collection.csv"); do python3 $R/scripts/pmc_summary.py $f 0 > $(dirname $f)/summary.txt; done
 find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name "*kernel_trace.csv" -delete

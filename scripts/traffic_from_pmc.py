@@ -12,7 +12,8 @@ import sys
 
 root = sys.argv[1]
 # name -> (key in profiles/hbm_traffic.json, sweeps per profiled run = 2 x (warmup + steps) of scripts/profile_round.sh)
-RUNS = {"pg10": ("C4_pg_maxupd10_f32", 12), "pg1": ("C4_pg_maxupd1_f32", 12), "cg64": ("C4_cg_maxupd5_f64", 6)}
+RUNS = {"pg10": ("C4_pg_maxupd10_f32", 12), "pg1": ("C4_pg_maxupd1_f32", 12), "cg64": ("C4_cg_maxupd5_f64", 6),
+        "cg32": ("C4_cg_maxupd5_f32", 6), "tncg32": ("C4_tncg_f32", 6)}
 
 
 def total(path, counter):
@@ -20,7 +21,7 @@ def total(path, counter):
     for line in open(path):
         if not line.startswith(" "):
             name = line.strip()
-        elif name and "half_sweep" in name and counter in line:
+        elif name and ("half_sweep" in name or "eep_lane_kernel" in name) and counter in line:   # (summaries cut names to their tail)
             tot += float(re.search(r"sum=([0-9.e+]+)", line).group(1))
     return tot
 
@@ -29,6 +30,13 @@ out = {"_note": "fabric-side bytes per full sweep of the half_sweep_* launches o
                 "(2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes "
                 "(scripts/profile_round.sh); Infinity-Cache hits are included, so this is an upper bound on DRAM traffic"}
 for name, (key, sweeps) in RUNS.items():
+    # the key bench.py looks up: <workload>_<method>_maxupd<N>_<f32|f64>, read off the bench line of the same run when it is there
+    try:
+        d = json.loads(open(os.path.join(root, f"kt_{name}_bench_line.json")).read())
+        m = re.search(r"method=(\w+), maxupd=(\d+)", d["config"]["workload"])
+        key = f"C4_{m.group(1)}_maxupd{m.group(2)}_{d['dtype']}"
+    except Exception:
+        pass
     ff = glob.glob(os.path.join(root, f"pmc_f_{name}", "**", "summary.txt"), recursive=True)
     ww = glob.glob(os.path.join(root, f"pmc_w_{name}", "**", "summary.txt"), recursive=True)
     if ff and ww:

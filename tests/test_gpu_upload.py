@@ -1,0 +1,48 @@
+"""The boundary's host <-> device copies (poismf_amd/csrc/devmem.hpp): arrays of 16 MB and more travel through pinned chunks
+filled by a few host threads -- indices narrowed from size_t to u32 on the way -- and the factors come back the same way.  The
+copies must be invisible: run_poismf on the same input gives the same BITS whether the staged path is taken (forced here by
+lowering its threshold so that every array is cut into many chunks, with ragged last chunks per thread), not taken at all, or
+taken with another number of threads.  The knobs are read once per process, hence the children.  Needs an MI355X."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from tests import helpers as H
+from tests.test_gpu_parity import gpu_run
+dimA, dimB, k = 30000, 9000, 50
+csr, csc, A0, B0 = H.small_problem(dimA, dimB, 1500000, k, {prec!r}, seed=21, powerlaw=True, empty_rows=(5, 29999))
+A, B, _ = gpu_run(csr, csc, A0, B0, {method!r}, 2, k)
+np.save({out!r}, np.concatenate([A.ravel(), B.ravel()]))
+"""
+
+
+@pytest.mark.parametrize("prec,method", [(True, "pg"), (False, "cg")], ids=["f32-pg", "f64-cg"])
+def test_staged_copies_leave_no_trace(prec, method, tmp_path):
+    runs = {
+        "plain": {"POISMF_HIP_NO_STAGED_UPLOAD": "1"},
+        # 1.5M nonzeros: 6 MB of indices / 6-12 MB of values per half, 6-12 MB of factors; 4 MB chunks, so 3 and 7 threads
+        # give every thread a ragged single chunk or a few chunks with a short tail
+        "staged3": {"POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "3"},
+        "staged7": {"POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "7"},
+        "staged1": {"POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "1"},
+    }
+    res = {}
+    for tag, env in runs.items():
+        out = str(tmp_path / f"{tag}.npy")
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, prec=prec, method=method, out=out)], check=True, env=e, cwd=ROOT,
+                       timeout=600)
+        res[tag] = np.load(out)
+    assert np.isfinite(res["plain"]).all() and res["plain"].any()
+    for tag in ("staged3", "staged7", "staged1"):
+        assert np.array_equal(res[tag], res["plain"]), tag
