@@ -74,6 +74,11 @@ def main():
     dt = (time.time() - t0) / a.sweeps
     kms = [s.kernel_time(w) for w in (0, 1)]
     A1, B1 = s.get_factors()
+    launches = []
+    if not os.environ.get("RUN_CONFIG_NO_PROFILE"):
+        for w in (0, 1):
+            for L in s.launch_profile(w):
+                launches.append(dict(half="A" if w else "B", kernel=L["kernel"], rows=L["rows"], nnz=L["nnz"], ms_per_call=L["ms"] / max(L["calls"], 1)))
     sz = 4 if use_float else 8
     bytes_sweep = sum(n * (4 + sz + k * sz) + 2 * d * k * sz + (d + 1) * 8 for n, d in ((nnz, dimA), (nnz, dimB)))
     kern = (kms[0][0] + kms[1][0]) / a.sweeps
@@ -81,7 +86,7 @@ def main():
                maxupd=maxupd, ms_per_sweep=dt * 1e3, nnz_per_s=nnz / dt, kernel_ms_per_sweep=kern,
                kernel_ms_B_half=kms[0][0] / a.sweeps, kernel_ms_A_half=kms[1][0] / a.sweeps,
                roofline_frac=bytes_sweep / (kern * 1e-3) / 8e12, data_build_s=t_data, upload_s=t_up,
-               finite=bool(np.isfinite(A1).all() and np.isfinite(B1).all()))
+               finite=bool(np.isfinite(A1).all() and np.isfinite(B1).all()), launches=launches)
     # sampled-row parity of the LAST sweep's A half (it used B1 as the fixed factor; its input rows are unknown
     # for CG/TNCG after the B half only changed B, so the A rows entering the A half are prevA)
     if a.sample > 0:

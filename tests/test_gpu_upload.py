@@ -20,13 +20,15 @@ from tests import helpers as H
 from tests.test_gpu_parity import gpu_run
 dimA, dimB, k = 30000, 9000, 50
 csr, csc, A0, B0 = H.small_problem(dimA, dimB, 1500000, k, {prec!r}, seed=21, powerlaw=True, empty_rows=(5, 29999))
-A, B, _ = gpu_run(csr, csc, A0, B0, {method!r}, 2, k)
+A, B, _ = gpu_run(csr, csc, A0, B0, {method!r}, 2, k, **{kw!r})
 np.save({out!r}, np.concatenate([A.ravel(), B.ravel()]))
 """
 
 
-@pytest.mark.parametrize("prec,method", [(True, "pg"), (False, "cg")], ids=["f32-pg", "f64-cg"])
-def test_staged_copies_leave_no_trace(prec, method, tmp_path):
+# (PG with the step / l2 of bench.py's "finite" block: the Python defaults drive every factor entry to exact zero, which would
+# compare equal whatever the copies did)
+@pytest.mark.parametrize("prec,method,kw", [(True, "pg", dict(l2_reg=1e3, step_size=1e-9)), (False, "cg", {})], ids=["f32-pg", "f64-cg"])
+def test_staged_copies_leave_no_trace(prec, method, kw, tmp_path):
     runs = {
         "plain": {"POISMF_HIP_NO_STAGED_UPLOAD": "1"},
         # 1.5M nonzeros: 6 MB of indices / 6-12 MB of values per half, 6-12 MB of factors; 4 MB chunks, so 3 and 7 threads
@@ -40,7 +42,7 @@ def test_staged_copies_leave_no_trace(prec, method, tmp_path):
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
         e.update(env)
-        subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, prec=prec, method=method, out=out)], check=True, env=e, cwd=ROOT,
+        subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, prec=prec, method=method, kw=kw, out=out)], check=True, env=e, cwd=ROOT,
                        timeout=600)
         res[tag] = np.load(out)
     assert np.isfinite(res["plain"]).all() and res["plain"].any()
