@@ -139,8 +139,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr bool DIRECT_A = PMF_LANE_DIRECT && PMF_LANE_DIRECT_A;
     static constexpr bool STAGED = LL_ > 0 || (LA_ > 0 && !DIRECT_A) || !PMF_LANE_DIRECT;   // some set travels through LDS
     static constexpr int NBUF = LL_ > 0 ? LL_ * NCH : (!STAGED ? 0 : (SMALL_ ? 1 : 2));  // staging buffers; the chunks of the LDS sets stay in theirs
-    static constexpr bool ALIAS = SMALL_ && NBUF > 0;
-    static_assert(!SMALL_ || LL_ == 0, "the shared buffer is free once the gather is done");
+    static constexpr bool ALIAS = SMALL_ && NBUF > 0 && LL_ == 0;   // (with an LDS set the buffers hold the tile: the scratch gets its own bytes)
     static_assert(KP % NC == 0, "blocks of equal size");
     static constexpr int DB = KP / NC;                    // dimensions per 64-lane block
     static constexpr int CW = (DB + 3) / 4;               // columns: dimension d' of a block lives in lane (d' % CW) + 16 (d' / CW)
@@ -157,6 +156,12 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
     static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) : 0;
     static constexpr int SMEM_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;
+#ifndef PMF_LANE_SPOINT
+#define PMF_LANE_SPOINT 1   // floats, all sets in registers: the point reaches the dots as SCALAR operands (set_point keeps it in a register,
+                            // lane <-> dimension; eval() takes dimension c with one v_readlane and multiplies by the SGPR) instead of an LDS
+                            // copy read back by broadcast -- no LDS round trip anywhere in the dots; same order of additions, same bits
+#endif
+    static constexpr bool SPOINT = PMF_LANE_SPOINT && sizeof(T) == 4 && NC == 1 && LLT == 0;
     static constexpr bool PIPELINED = true;
     static constexpr bool PARKS = false;
     static constexpr bool CACHED = true, MAY_CACHE = true, CACHED_GRAD = true;
@@ -178,6 +183,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     U2 pfx[PF_ ? 2 : 1];        // AGPR-class: the next row's values
     U2 pfm[PF_ ? NC : 1];       // AGPR-class: the next row's starting point (its row of the factor being updated)
     T xt[NC];                   // the current row's starting point, as take_prefetched left it
+    T xcur;              // SPOINT: the current point, element of this lane's dimension (0 in lanes that hold none)
     T xr[LT];            // x_j of this lane's nonzeros
     unsigned idx_n[LT];  // column indices of the row whose tile is requested next (fetch_meta -> gather)
     T pv[LT], qv[LT];    // cached predictions p_j = F_j . x and q_j = F_j . d (solvers.hpp, cg_row_cached)
@@ -556,6 +562,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 
     __device__ __forceinline__ void set_point(const T (&x)[NC])
     {
+        if constexpr (SPOINT) { xcur = act[0] ? x[0] : (T)0; return; }
         T* a = (T*)avec;
         wave_lds_fence();
 #pragma unroll
@@ -652,13 +659,14 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         static_for<0, CW>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             if constexpr (c + 1 < CW) load_col<B, c + 1>(tl[(c + 1) & 1]);
-            pin_here();
+            if constexpr (LLT > 0) pin_here();   // (no LDS set: nothing to hold back, and the columns' dependent chains -- four multiply-adds, swap,
+                                                 // add, swap, add -- are better interleaved than run one after the other)
             const T x = level_a<B, c, 0>(coef, tl[c & 1]);         // rows 0 | 2
             T o;
             if constexpr (c + CW < DB) o = swap_fold<16>(x, level_a<B, c, 1>(coef, tl[c & 1]));   // rows 1 | 3
             else o = swap_fold<16>(x, x);
             *(T*)(wr + (c % RED_COLS) * RED_STRIDE) = o;             // lane (R, p): dimension c + CW R, summed over the four lanes (., p)
-            pin_here();
+            if constexpr (LLT > 0) pin_here();
             // the last column of a group: lane (R, c') adds up column c' of the group over the 16 lanes of its row
             if constexpr ((c + 1) % RED_COLS == 0 || c + 1 == CW) {
                 constexpr int c_first = c / RED_COLS * RED_COLS;
@@ -723,6 +731,31 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         if constexpr (FROM_CACHE) {
 #pragma unroll
             for (int s = 0; s < LT; s++) pred[s] = pv[s];
+        } else if constexpr (SPOINT) {
+            // dimension c of the point sits in lane (c % CW) + 16 (c / CW): one v_readlane, then a scalar operand of LT multiply-adds
+            // (read in groups of GS ahead of their use: a v_readlane's SGPR needs two wait states before a VALU may read it)
+            constexpr int GS = 4;
+            static_for<0, (KP + GS - 1) / GS>([&](auto gc) {
+                constexpr int c0 = decltype(gc)::value * GS;
+                T ac[GS];
+                static_for<0, GS>([&](auto ic) {
+                    constexpr int c = c0 + decltype(ic)::value;
+                    if constexpr (c < KP) {
+                        ac[c - c0] = read_lane(xcur, (c % CW) + 16 * (c / CW));
+                        asm volatile("" : "+s"(ac[c - c0]));   // here, not sunk next to its use
+                    }
+                });
+                static_for<0, GS>([&](auto ic) {
+                    constexpr int c = c0 + decltype(ic)::value;
+                    if constexpr (c < KP) {
+                        static_for<0, LT>([&](auto sc) {
+                            constexpr int s2 = decltype(sc)::value;
+                            if constexpr (c == 0) pred[s2] = t[s2][c] * ac[c - c0];
+                            else pred[s2] = fma_t(t[s2][c], ac[c - c0], pred[s2]);
+                        });
+                    }
+                });
+            });
         } else {
             // slots in groups of GQ: the point (a broadcast read) and the LDS sets' slots of the NEXT group are requested
             // before the current group's multiply-adds

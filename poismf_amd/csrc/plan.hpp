@@ -205,6 +205,10 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
 #define PMF_LANE_PG32 0   // measured, C4 matrix, PG(10) fp32, B half: 9.5 ms against 8.0 ms for reg_eval.hpp's eight-wave kernels: a pass of
                           // either is ~5 k cycles of barrier / LDS round trips in lockstep, which the cheaper instruction stream does not shorten
 #endif
+#ifndef PMF_LANE_PG32X4
+#define PMF_LANE_PG32X4 1   // rows of 513 .. 1024 nonzeros on FOUR waves of four sets each (three in registers, one in LDS), two such rows per CU
+#endif
+            if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1 };
             if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };
             if (PMF_LANE_PG32 && cls > 1024 && cls <= 1536) return { 3, 0, 0, 8, 1 };
             return { 0, 0, 0, 0, 0 };

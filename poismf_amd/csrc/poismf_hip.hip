@@ -645,6 +645,7 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
                 switch (key) {
                     case 20081: return launch_lane<METHOD, 13, 2, 0, 0, 8, true>(stream, a, grid_mult);
                     case 30081: return launch_lane<METHOD, 13, 3, 0, 0, 8, true>(stream, a, grid_mult);
+                    case 40041: return launch_lane<METHOD, 13, 4, 0, 0, 4, true>(stream, a, grid_mult);
                 }
             } else {
                 switch (key) {
