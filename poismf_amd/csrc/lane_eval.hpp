@@ -161,7 +161,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                             // lane <-> dimension; eval() takes dimension c with one v_readlane and multiplies by the SGPR) instead of an LDS
                             // copy read back by broadcast -- no LDS round trip anywhere in the dots; same order of additions, same bits
 #endif
-    static constexpr bool SPOINT = PMF_LANE_SPOINT && sizeof(T) == 4 && NC == 1 && LLT == 0;
+    // (only where four or more sets share each v_readlane: with the one to three sets of the CG / TNCG instances the 52 readlanes of an
+    // evaluation cost more than 13 broadcast reads -- C2 CG fp32 2.20 -> 2.58 ms, TNCG fp32 12.6 -> 13.5 with it)
+    static constexpr bool SPOINT = PMF_LANE_SPOINT && sizeof(T) == 4 && NC == 1 && LLT == 0 && LV_ >= 4;
     static constexpr bool PIPELINED = true;
     static constexpr bool PARKS = false;
     static constexpr bool CACHED = true, MAY_CACHE = true, CACHED_GRAD = true;
@@ -641,13 +643,29 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         });
         return v;
     }
+    // swap_fold for the transposing reduction.  Floats: through the LDS crossbar (ds_bpermute: the partner's copy of what this
+    // lane collects) -- two selects and an add on the VALU (6 cycles) where v_permlane32_swap + add cost 12 (the swap alone ~10,
+    // scripts/probes/valu_probe.hip); its latency is the other wave's issue time at two waves per SIMD.  The same sum, the same
+    // bits.  Doubles (one wave per SIMD, nothing to hide a round trip behind) keep the swaps.
+#ifndef PMF_LANE_BPERM32
+#define PMF_LANE_BPERM32 0   // measured: PG item rows 4.86 -> 5.19 ms, C2 CG fp32 2.20 -> 2.97, TNCG fp32 12.6 -> 17.2: the round trip sits in every dependent chain of the reduction
+#endif
+    template <int W_> __device__ __forceinline__ T fold(T a, T b) const
+    {
+        if constexpr (sizeof(T) == 4 && PMF_LANE_BPERM32) {
+            const bool up = (lane & W_) != 0;
+            const T send = up ? a : b, mine = up ? b : a;
+            const int got = __builtin_amdgcn_ds_bpermute((lane ^ W_) * 4, __builtin_bit_cast(int, send));
+            return mine + __builtin_bit_cast(T, got);
+        } else return swap_fold<W_>(a, b);
+    }
     // the two dimensions COL + CW R0 (kept by the lanes of the lower half-wave) and COL + CW (R0 + 2) (upper) of block B
     template <int B, int COL, int R0> __device__ __forceinline__ T level_a(const T (&coef)[LT], const T (&tl)[4][LLX]) const
     {
         static_assert(COL + CW * R0 < DB, "a dimension of the block");
         const T a = partial<B, COL, R0>(coef, tl);
-        if constexpr (COL + CW * (R0 + 2) < DB) return swap_fold<32>(a, partial<B, COL, R0 + 2>(coef, tl));
-        else return swap_fold<32>(a, a);   // (the upper half-wave's result belongs to no dimension)
+        if constexpr (COL + CW * (R0 + 2) < DB) return fold<32>(a, partial<B, COL, R0 + 2>(coef, tl));
+        else return fold<32>(a, a);   // (the upper half-wave's result belongs to no dimension)
     }
     template <int B> __device__ __forceinline__ T reduce_block(const T (&coef)[LT])
     {
@@ -663,8 +681,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                                                  // add, swap, add -- are better interleaved than run one after the other)
             const T x = level_a<B, c, 0>(coef, tl[c & 1]);         // rows 0 | 2
             T o;
-            if constexpr (c + CW < DB) o = swap_fold<16>(x, level_a<B, c, 1>(coef, tl[c & 1]));   // rows 1 | 3
-            else o = swap_fold<16>(x, x);
+            if constexpr (c + CW < DB) o = fold<16>(x, level_a<B, c, 1>(coef, tl[c & 1]));   // rows 1 | 3
+            else o = fold<16>(x, x);
             *(T*)(wr + (c % RED_COLS) * RED_STRIDE) = o;             // lane (R, p): dimension c + CW R, summed over the four lanes (., p)
             if constexpr (LLT > 0) pin_here();
             // the last column of a group: lane (R, c') adds up column c' of the group over the 16 lanes of its row
