@@ -136,8 +136,21 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                               // landed (1.6 KB of scratch per lane, wrong tiles).  The staged path writes the same registers with
                               // v_accvgpr_write from data that is there.
 #endif
-    static constexpr bool DIRECT_A = PMF_LANE_DIRECT && PMF_LANE_DIRECT_A;
-    static constexpr bool STAGED = LL_ > 0 || (LA_ > 0 && !DIRECT_A) || !PMF_LANE_DIRECT;   // some set travels through LDS
+#ifndef PMF_LANE_STAGE_V
+#define PMF_LANE_STAGE_V 0   // instances with AGPR sets stage the VGPR set through LDS as well (fewer tag look-ups, one more round trip): C3 B half 18.8 -> 18.7 ms, within noise; off
+#endif
+    static constexpr bool DIRECT_V = PMF_LANE_DIRECT && !(PMF_LANE_STAGE_V && LA_ > 0 && sizeof(T) == 8);
+    static constexpr bool DIRECT_A = DIRECT_V && PMF_LANE_DIRECT_A;
+#ifndef PMF_LANE_TEMP_A
+#define PMF_LANE_TEMP_A 0   // the AGPR sets by plain per-lane loads into architectural registers (free between two rows: the solver's state is
+                            // dead) and v_accvgpr_write from there -- no staging buffers, so the LDS sets' DMA is requested FIRST and is in
+                            // flight together with the register sets': two trips to memory per row instead of three.  Measured, C3 B half,
+                            // the 78.7 k rows of <= 1024 nonzeros: 13.2 -> 15.6 ms (maxupd 1: 7.3 -> 9.6).  A per-lane load instruction names
+                            // 64 different factor rows -- 64 tag look-ups in the texture path -- where a DMA chunk instruction covers five
+                            // (13 adjacent lanes per row): the gather is bound by look-ups, not by round trips.  Off.
+#endif
+    static constexpr bool TEMP_A = PMF_LANE_TEMP_A && DIRECT_V && !DIRECT_A && LA_ > 0;
+    static constexpr bool STAGED = LL_ > 0 || (LA_ > 0 && !DIRECT_A && !TEMP_A) || !DIRECT_V;   // some set travels through LDS
     static constexpr int NBUF = LL_ > 0 ? LL_ * NCH : (!STAGED ? 0 : (SMALL_ ? 1 : 2));  // staging buffers; the chunks of the LDS sets stay in theirs
     static constexpr bool ALIAS = SMALL_ && NBUF > 0 && LL_ == 0;   // (with an LDS set the buffers hold the tile: the scratch gets its own bytes)
     static_assert(KP % NC == 0, "blocks of equal size");
@@ -150,7 +163,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr int RED_PH = LP_ > 0 ? 2 : 1;        // the columns pass through the scratch in this many groups
     static constexpr int RED_COLS = RED_PH == 1 ? 16 : (CW + 1) / 2;
     static constexpr int RED_BYTES = 4 * RED_COLS * RED_STRIDE; // four 16-lane rows x the columns of a group
-    static constexpr int PART_BYTES = LP_ * W * 16;       // one chunk of the partial set
+    // one chunk of the partial set: LP_ rows of W slots, rounded up to whole DMA instructions (64 lanes x 16 bytes) so that no
+    // lane has to be masked off -- the lanes past the image fetch some row's slots into the padding
+    static constexpr int PART_BYTES = LP_ > 0 ? (LP_ * W * 16 + 1023) / 1024 * 1024 : 0;
     static constexpr int AVEC_BYTES = (KP * (int)sizeof(T) + 15) / 16 * 16;
     static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES) + AVEC_BYTES;
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
@@ -475,8 +490,21 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         // KS loads in flight per lane, no staging, no address arithmetic beyond the row's base.  (64 different rows per
         // instruction: the price is in the texture unit -- 64 tag look-ups per instruction -- which a row pays once; the lines
         // are the same 2-4 per row that a coalesced fetch would bring.)
-        constexpr int S0 = PMF_LANE_DIRECT ? (DIRECT_A ? LR : LV) : 0;   // first set that goes through the staging buffers
-        if constexpr (PMF_LANE_DIRECT) {
+        constexpr int S0 = DIRECT_V ? ((DIRECT_A || TEMP_A) ? LR : LV) : 0;   // first set that goes through the staging buffers
+        auto request_lds_sets = [&]() {
+            static_for<0, LL * NCH>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                dma_chunk<chunk_start(w % NCH)>(idx[LR + w / NCH], w);
+            });
+            if constexpr (LP > 0) {
+                static_for<0, NCH>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    dma_chunk_part<chunk_start(c)>(idx[LT - 1], c);
+                });
+            }
+        };
+        if constexpr (TEMP_A && LL > 0) request_lds_sets();   // nothing is staged: their buffers are free now
+        if constexpr (DIRECT_V) {
             const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
             static_for<0, LV>([&](auto sc) {
                 constexpr int s2 = decltype(sc)::value;
@@ -497,6 +525,29 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             static_for<0, LA>([&](auto sc) {
                 constexpr int s2 = decltype(sc)::value;
                 acc_load_set<s2>((const char*)F + (size_t)__umul24(idx[LV + s2], rowbytes));
+            });
+        }
+        if constexpr (TEMP_A) {
+            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+            static_for<0, LA>([&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                const char* base = (const char*)F + (size_t)__umul24(idx[LV + s2], rowbytes);
+                typename Slot<T>::U tmp[KS];
+                static_for<0, KS>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    tmp[q] = *(const typename Slot<T>::U*)(base + q * 16);
+                });
+                static_for<0, KS>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+#pragma unroll
+                    for (int e = 0; e < SN; e++) {
+                        if constexpr (sizeof(T) == 8) {
+                            const unsigned long long b = __builtin_bit_cast(unsigned long long, tmp[q].v[e]);
+                            tae[s2][q * SN + e][0] = acc_put((unsigned)b);
+                            tae[s2][q * SN + e][1] = acc_put((unsigned)(b >> 32));
+                        } else tae[s2][q * SN + e][0] = acc_put(__builtin_bit_cast(unsigned, tmp[q].v[e]));
+                    }
+                });
             });
         }
         // (without direct loads) the register sets' chunks pass through the staging buffers, NBUF in flight
@@ -526,20 +577,12 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         if constexpr (ALIAS) { __builtin_amdgcn_s_waitcnt(0xc07f); wave_lds_fence(); }   // the scratch of the reductions is this buffer
         // LDS sets: their chunks stay in the buffers (set u, chunk c in buffer u NCH + c)
         if constexpr (LL > 0) {
-            static_for<0, LL * NCH>([&](auto wc) {
-                constexpr int w = decltype(wc)::value;
-                dma_chunk<chunk_start(w % NCH)>(idx[LR + w / NCH], w);
-            });
-            if constexpr (LP > 0) {
-                static_for<0, NCH>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    dma_chunk_part<chunk_start(c)>(idx[LT - 1], c);
-                });
-            }
+            if constexpr (!TEMP_A) request_lds_sets();
             wait_dma<0>();
         }
     }
-    // the same for the partial set: LP rows, ceil(LP W / 64) instructions, the lanes past the image masked off
+    // the same for the partial set: LP rows, ceil(LP W / 64) instructions (ds_bpermute takes its lane index modulo 64: the lanes past
+    // the image name rows of the set's first lanes)
     template <int Q0> __device__ __forceinline__ void dma_chunk_part(unsigned idx, int c)
     {
         const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
@@ -551,9 +594,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             constexpr int i = decltype(ic)::value;
             const unsigned col = (unsigned)__builtin_amdgcn_ds_bpermute((int)j4, (int)idx);
             const unsigned off = __umul24(col, rowbytes) + q16 + (unsigned)(Q0 * 16);
-            if (j4 < (unsigned)(LP * 4))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)F + (size_t)off),
-                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)F + (size_t)off),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
             j4 += (unsigned)(WAVE / W) * 4u;
             q16 += (unsigned)(WAVE % W) * 16u;
             const bool wrap = q16 >= (unsigned)(W * 16);

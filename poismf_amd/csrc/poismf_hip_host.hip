@@ -975,10 +975,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
         if (lane_ok) {
             const LaneShape ls = lane_shape_for(b.cls, g.s_load, p->method);
-            // (the instance with a partial LDS set is bit-reproducible under CG and PG; under TNC -- 524 bytes of scratch per
-            // lane -- its results were seen to change between runs: it stays behind a testing knob until that is understood)
-            static const bool lp_tncg = getenv("POISMF_HIP_LP_TNCG") != nullptr;
-            if (ls.waves > 0 && (ls.lp == 0 || p->method != POISMF_TNCG || lp_tncg)) {
+            if (ls.waves > 0) {
                 if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp &&
                     launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)
                     { launches.back().count += b.count; launches.back().nnz += b.nnz; }

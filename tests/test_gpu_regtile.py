@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from poismf_amd import harness
+from poismf_amd import api, harness
 from tests import helpers as H
 from tests.test_gpu_parity import compare, gpu_run, oracle_run
 
@@ -170,3 +170,22 @@ def test_tile_pass_counters(k):
         assert passes == 2 * 3 * int((nnz > 0).sum())
         assert nnz_passes == 2 * 3 * int(nnz.sum())
     s.close()
+
+
+@pytest.mark.parametrize("method,maxupd", [("cg", 5), ("tncg", 40), ("pg", 2)])
+def test_partial_lds_set_rows_repeat_bit_for_bit(method, maxupd):
+    """fp64, k = 50, rows of 1025 .. 1088 nonzeros: the lane instance with a PARTIAL LDS set (lane_eval.hpp, LP_).  Its 16-row
+    chunk images were first fetched by an LDS-DMA instruction under an exec mask (lanes past the image switched off); under TNCG
+    -- the instance with the most scratch -- the results then changed from run to run, although CG and PG came out identical
+    every time.  The DMA now always runs with all 64 lanes into a padded image.  Three runs of the same rows, same bits."""
+    k = 50
+    lengths = [1024, 1025, 1026, 1030, 1040, 1041, 1056, 1072, 1087, 1088] * 6
+    csr, csc, A0, B0 = ragged_problem(lengths, 4000, k, False, seed=5)
+    val, ind, ptr = csr
+    l2, _, _ = harness.auto_defaults(method, k)
+    bs = B0.sum(axis=0)
+    kw = dict(l2_reg=1e3, step_size=1e-9) if method == "pg" else dict(l2_reg=l2)   # (PG's defaults zero every entry)
+    runs = [api._predict_factors_multiple(B0, bs, A0.mean(axis=0), ptr, ind, val, w_mult=1.0, niter=1, maxupd=maxupd, method=method,
+                                          limit_step=True, reuse_mean=False, **kw) for _ in range(3)]
+    assert np.isfinite(runs[0]).all() and runs[0].any()
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
