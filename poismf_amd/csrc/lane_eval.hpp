@@ -160,7 +160,14 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // bytes between the 16-element rows of the transpose scratch: 18 doubles / 20 floats -- 36 c / 20 c banks for column c are
     // sixteen different multiples of 4 (mod 64), so the 16 lanes of a ds_read_b128 service group never share a bank
     static constexpr int RED_STRIDE = sizeof(T) == 8 ? 18 * 8 : 20 * 4;
-    static constexpr int RED_PH = LP_ > 0 ? 2 : 1;        // the columns pass through the scratch in this many groups
+#ifndef PMF_LANE_FIVE
+#define PMF_LANE_FIVE 0   // doubles, one VGPR set + one LDS set, one wave per row: the scratch in two halves brings a wave's LDS from 36.3 to 31.1 KB,
+                          // i.e. FIVE rows per CU instead of four, one SIMD taking two waves.  Measured, C3 A half: 19.8 -> 23.9 ms (maxupd 1:
+                          // 10.0 -> 14.1): CG's instance needs 256 VGPRs + 44 AGPRs as it is, and held to 256 registers it spills 172 bytes
+                          // per lane into the evaluation loops -- a fifth row does not pay for that.  Off.
+#endif
+    static constexpr bool FIVE = PMF_LANE_FIVE && sizeof(T) == 8 && LV_ == 1 && LA_ == 0 && LL_ == 1 && NW_ == 1 && !PF_ && LP_ == 0;
+    static constexpr int RED_PH = (LP_ > 0 || FIVE) ? 2 : 1;        // the columns pass through the scratch in this many groups
     static constexpr int RED_COLS = RED_PH == 1 ? 16 : (CW + 1) / 2;
     static constexpr int RED_BYTES = 4 * RED_COLS * RED_STRIDE; // four 16-lane rows x the columns of a group
     // one chunk of the partial set: LP_ rows of W slots, rounded up to whole DMA instructions (64 lanes x 16 bytes) so that no

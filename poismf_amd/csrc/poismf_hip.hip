@@ -488,8 +488,14 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
 
 // Lane-per-nonzero engine (lane_eval.hpp): doubles, 25 or 50 slots per factor row; NW waves per row; one wave per SIMD, or
 // (SMALL: one register set, 14 KB of LDS per wave) two.
+// (lane_two: instances compiled for two waves per SIMD -- the SMALL ones, and CG on doubles with one VGPR set + one LDS set, whose
+// 31 KB of LDS per row let a CU take five rows, PMF_LANE_FIVE)
+template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF, int LP> constexpr bool lane_two()
+{
+    return SMALL || (LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP>::FIVE && METHOD == K_CG);
+}
 template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF = false, int LP = 0>
-__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(SMALL ? 2 : 1, SMALL ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(lane_two<T, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 2 : 1, lane_two<T, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
 {
     using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
@@ -605,7 +611,7 @@ template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false
         using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, PF, LP>;
         auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>;
         // workgroups per CU: one (SMALL: two) waves per SIMD, and the LDS each takes
-        const int occ = std::max(1, std::min((SMALL ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
+        const int occ = std::max(1, std::min((lane_two<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
         const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)t_num_cu * (size_t)occ * grid_mult);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW), 0, stream, a);
         HIP_TRY(hipGetLastError());
