@@ -273,6 +273,12 @@ POISMF_HIP_API int poismf_hip_factors_multiple_decisions(real_t *A, real_t *B, r
                           real_t step_size, size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean,
                           unsigned *decisions);
 
+/* Testing aid (G1): the device's own objective / gradient wrappers at `point`, for every row of a CSR, through whichever row engine a CG
+ * half-sweep would use for a row of that length.  which = 0: calc_fun_single + calc_grad_single[_w] (ref src/poismf.c:194-240);
+ * which = 1: calc_fun_and_grad (ref src/poismf.c:242-273; no l2 term in f).  G [dimA x k] receives the gradients, f [dimA] the values. */
+POISMF_HIP_API int poismf_hip_debug_row_eval(real_t *G, double *f, real_t *B, real_t *Bsum, real_t *point, real_t *Xr,
+                          sparse_ix *Xr_indptr, sparse_ix *Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, int which);
+
 /* Number of nonzeros held by this session for half `which` (shard only). */
 POISMF_HIP_API size_t poismf_hip_session_nnz(poismf_hip_session *s, int which);
 

@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_create_coo", "poismf_hip_session_stream", "poismf_hip_session_factors_dirty", "poismf_hip_session_run",
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
     "poismf_hip_session_launch_profile", "poismf_hip_session_decisions", "poismf_hip_factors_multiple_decisions",
-    "poismf_hip_session_predict", "poismf_hip_session_topn",
+    "poismf_hip_session_predict", "poismf_hip_session_topn", "poismf_hip_debug_row_eval",
 )
 
 
@@ -261,6 +261,26 @@ def factors_multiple_with_decisions(B, Bsum, Amean, Xr_indptr, Xr_indices, Xr, l
     if ret:
         raise MemoryError("Could not allocate enough memory.")
     return A, (dec[:, 0] & 0xffffff).astype(np.int64), dec[:, 1].astype(np.int64), (dec[:, 0] >> 24).astype(np.int64)
+
+
+def debug_row_eval(B, Bsum, point, Xr_indptr, Xr_indices, Xr, l2_reg, w_mult=1., which=0):
+    """Testing aid (include/poismf_hip.h, poismf_hip_debug_row_eval): the device's fun_single + grad_single (which = 0) or fun_and_grad
+    (which = 1) at `point` for every row of the CSR; returns (f [n] float64, G [n x k])."""
+    use_float = B.dtype == np.float32
+    _check_arrays(use_float, (B, Bsum, point, Xr), (Xr_indptr, Xr_indices))
+    lib = load_library(use_float)
+    k = B.shape[1]
+    n = Xr_indptr.shape[0] - 1
+    G = np.empty((n, k), dtype=B.dtype)
+    f = np.empty(n, dtype=np.float64)
+    real = C.c_float if use_float else C.c_double
+    fn = lib.poismf_hip_debug_row_eval
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 8 + [C.c_int, C.c_size_t, real, real, C.c_int]
+    ret = fn(_ptr(G), _ptr(f), _ptr(B), _ptr(Bsum), _ptr(point), _ptr(Xr), _ptr(Xr_indptr), _ptr(Xr_indices), k, n, l2_reg, w_mult, int(which))
+    if ret:
+        raise MemoryError("poismf_hip_debug_row_eval failed")
+    return f, G
 
 
 class PoisMF:

@@ -20,13 +20,14 @@ CSRC = os.path.join(HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "poismf_hip.h")
 _ROW = ["poismf_hip.hip", "plan.hpp", "devmem.hpp", "solvers.hpp", "row_eval.hpp", "reg_eval.hpp", "lane_eval.hpp", "wave_ops.hpp"]
 _HOST = ["poismf_hip_host.hip", "plan.hpp", "devmem.hpp", "row_eval.hpp", "wave_ops.hpp"]
-# unit -> (source files, first is the one compiled; extra flags).  poismf_hip.hip is compiled three times: one
+# unit -> (source files, first is the one compiled; extra flags).  poismf_hip.hip is compiled four times: one
 # translation unit per inner solver (its row kernels are the bulk of the compile time); the host side is its own file.
 UNITS = {
     "poismf_hip_host": (_HOST, []),
     "poismf_hip_tncg": (_ROW, ["-DPMF_TU=1"]),
     "poismf_hip_cg": (_ROW, ["-DPMF_TU=2"]),
     "poismf_hip_pg": (_ROW, ["-DPMF_TU=3"]),
+    "poismf_hip_eval": (_ROW, ["-DPMF_TU=4"]),   # evaluation-only kernels behind poismf_hip_debug_row_eval (testing aid)
     "coo_convert": (["coo_convert.hip", "devmem.hpp"], []),
     "serve": (["serve.hip"], []),
 }

@@ -978,6 +978,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         T one[LT];
 #pragma unroll
         for (int s = 0; s < LT; s++) one[s] = (T)1;   // lanes past the row's end hold the zero row
+        if constexpr (LP > 0) one[LT - 1] = lane < LP ? (T)1 : (T)0;   // (the partial set's lanes >= LP alias rows of its first lanes)
         T tot[NC];
         static_for<0, NC>([&](auto bc) {
             constexpr int b = decltype(bc)::value;

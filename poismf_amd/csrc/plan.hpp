@@ -64,7 +64,12 @@ template <class T> struct HalfArgs {
     const unsigned* gate;             // != nullptr: the kernel runs only if *gate != 0 (the streamed re-run of a team launch that gave up)
 };
 
-enum { K_PG = 3, K_CG = 2, K_TNCG = 1 };
+enum { K_PG = 3, K_CG = 2, K_TNCG = 1, K_EVAL = 4 };
+// K_EVAL / POISMF_EVAL: not a solver -- the row kernels evaluate the device's own fun_single + grad_single (RowParams::maxupd == 0) or
+// fun_and_grad (maxupd == 1) at each row's starting point and hand the gradient back in place of the updated row, the function
+// value through the decisions words (testing aid: poismf_hip_debug_row_eval, include/poismf_hip.h).  Planned like CG, so every
+// engine CG would pick for a row length is reachable; its kernels live in a translation unit of their own (PMF_TU=4).
+constexpr int POISMF_EVAL = 4;
 
 // One row of the sorted order: where its nonzeros start in the shard's CSR arrays, how many, and which row it is.
 struct RowDesc { unsigned p0_lo, p0_hi, nnz, lrow; };
@@ -256,3 +261,4 @@ struct OneLaunch {
 int pmf_launch_one_tu1(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
 int pmf_launch_one_tu2(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
 int pmf_launch_one_tu3(int method, const OneLaunch& o, const HalfArgs<real_t>& a);
+int pmf_launch_one_tu4(int method, const OneLaunch& o, const HalfArgs<real_t>& a);

@@ -1,5 +1,5 @@
 // poismf_hip.hip -- the row kernels of the MI355X implementation of poismf's alternating factor-update path and their
-// launchers.  Compiled once per inner solver and precision (-DPMF_TU=1 tncg / 2 cg / 3 pg; without it all three, the
+// launchers.  Compiled once per inner solver and precision (-DPMF_TU=1 tncg / 2 cg / 3 pg / 4 the evaluation-only kernels of poismf_hip_debug_row_eval; without it all three, the
 // -DPMF_TIMING development build) into libpoismf_hip_d.so / libpoismf_hip_f.so (-DUSE_FLOAT); the host side
 // (sessions, run_poismf, planning) is poismf_hip_host.hip, the C-ABI is declared in include/poismf_hip.h.
 //
@@ -70,7 +70,23 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
     }
 
     SolveStats st;
-    if constexpr (METHOD == K_PG) {
+    if constexpr (METHOD == K_EVAL) {
+        // G1 (plan.hpp, K_EVAL): the objective and gradient at the starting point, as the solvers' own wrappers compute them
+        T g[NC];
+        double f;
+        if (a.P.maxupd == 0) {
+            f = (double)fun_single(ev, a.P, shift, x);                  // ref: src/poismf.c:194-208
+            grad_single(ev, a.P, shift, x, g, weighted);                // ref: :210-240
+        } else f = (double)fun_and_grad(ev, a.P, shift, x, g);          // ref: :242-273 (no l2 term in f, quirk Q4)
+        ev.store_vec(out, g);
+        if (out_p != nullptr) ev.store_vec(out_p, g);
+        if (a.dec_rows != nullptr && ev.lane == 0 && ev.wid == 0 && ev.member == 0) {
+            const unsigned long long fb = __builtin_bit_cast(unsigned long long, f);
+            a.dec_rows[2 * (size_t)lrow] = (unsigned)fb;
+            a.dec_rows[2 * (size_t)lrow + 1] = (unsigned)(fb >> 32);
+        }
+        return;
+    } else if constexpr (METHOD == K_PG) {
         pg_row(ev, a.P, x, shift);
     } else if constexpr (METHOD == K_CG) {
         // cached line search: streamed rows of the LDS engine (plan_geom decides), fp64 single-wave rows of the register engine
@@ -535,6 +551,9 @@ template <int NC, int SL, int NW = 1> int launch_method(hipStream_t stream, int 
         case POISMF_CG:
             if constexpr (tu_has(K_CG)) return launch_bin<NC, K_CG, SL, NW>(stream, a, lds, grid);
             else return 1;
+        case POISMF_EVAL:
+            if constexpr (tu_has(K_EVAL)) return launch_bin<NC, K_EVAL, SL, NW>(stream, a, lds, grid);
+            else return 1;
         default:
             if constexpr (tu_has(K_TNCG)) return launch_bin<NC, K_TNCG, SL, NW>(stream, a, lds, grid);
             else return 1;
@@ -567,6 +586,9 @@ template <int S, int NS> int launch_reg_method(hipStream_t stream, int method, c
         case POISMF_CG:
             if constexpr (tu_has(K_CG) && S * REG_JG <= REG_NNZ_MAX_CG && (NS == 1 || S * REG_JG <= 144)) return launch_reg<K_CG, S, NS>(stream, a, grid_mult);
             else return 1;
+        case POISMF_EVAL:   // (the sizes CG has)
+            if constexpr (tu_has(K_EVAL) && S * REG_JG <= REG_NNZ_MAX_CG && (NS == 1 || S * REG_JG <= 144)) return launch_reg<K_EVAL, S, NS>(stream, a, grid_mult);
+            else return 1;
         default:
             if constexpr (tu_has(K_TNCG) && S * REG_JG <= REG_NNZ_MAX_TNCG && (NS == 1 || S * REG_JG <= 112)) return launch_reg<K_TNCG, S, NS>(stream, a, grid_mult);
             else return 1;
@@ -593,9 +615,10 @@ template <int METHOD, int S, int NS, int NW> int launch_regw(hipStream_t stream,
 // team launches: CG on doubles with two slots per lane (k = 50 fp64) is what asks for them
 template <int M, int S> int launch_team(hipStream_t stream, int method, const HalfArgs<real_t>& a)
 {
-    if constexpr (tu_has(K_CG) && sizeof(real_t) == 8 && REG_G == 16) {
-        if (method != POISMF_CG) return 1;
-        auto kern = half_sweep_team_kernel<real_t, K_CG, S, REG_G, 2, TEAM_NW, M>;
+    if constexpr ((tu_has(K_CG) || tu_has(K_EVAL)) && sizeof(real_t) == 8 && REG_G == 16) {
+        constexpr int KM = tu_has(K_CG) ? K_CG : K_EVAL;   // (the translation unit of the evaluation-only kernels has no CG)
+        if (method != (KM == K_CG ? POISMF_CG : POISMF_EVAL)) return 1;
+        auto kern = half_sweep_team_kernel<real_t, KM, S, REG_G, 2, TEAM_NW, M>;
         // as many workgroups as CUs: each takes a CU's whole register file (one wave of 512 per SIMD)
         const unsigned grid = (unsigned)std::min<size_t>((size_t)a.nrows * M, (size_t)t_num_cu / M * M);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * TEAM_NW), 0, stream, a);
@@ -679,6 +702,9 @@ template <int S, int NS, int NW> int launch_regw_method(hipStream_t stream, int 
         case POISMF_CG:
             if constexpr (tu_has(K_CG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_CG && NW <= 8) return launch_regw<K_CG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
+        case POISMF_EVAL:
+            if constexpr (tu_has(K_EVAL) && S * REG_JG <= REGW_WAVE_NNZ_MAX_CG && NW <= 8) return launch_regw<K_EVAL, S, NS, NW>(stream, a, grid_mult);
+            else return 1;
         default:
             if constexpr (tu_has(K_TNCG) && S * REG_JG <= REGW_WAVE_NNZ_MAX_TNCG && NW <= 8) return launch_regw<K_TNCG, S, NS, NW>(stream, a, grid_mult);
             else return 1;
@@ -726,6 +752,7 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
         if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
         if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
         if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
+        if (method == POISMF_EVAL) return launch_lane_shape<K_EVAL>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
         return 1;
     }
 #ifdef PMF_LANE_ONLY   // development: compile the lane-per-nonzero kernels alone (seconds instead of minutes)
@@ -775,6 +802,9 @@ int pmf_launch_one_tu2(int method, const OneLaunch& o, const HalfArgs<real_t>& a
 #endif
 #if PMF_TU == 3 || PMF_TU == -1
 int pmf_launch_one_tu3(int method, const OneLaunch& o, const HalfArgs<real_t>& a) { return launch_one_here(method, o, a); }
+#endif
+#if PMF_TU == 4 || PMF_TU == -1
+int pmf_launch_one_tu4(int method, const OneLaunch& o, const HalfArgs<real_t>& a) { return launch_one_here(method, o, a); }
 #endif
 
 #ifdef PMF_TIMING

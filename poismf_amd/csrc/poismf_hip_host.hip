@@ -22,7 +22,8 @@
 
 static int launch_one(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
 {
-    return method == POISMF_PG ? pmf_launch_one_tu3(method, o, a) : method == POISMF_CG ? pmf_launch_one_tu2(method, o, a) : pmf_launch_one_tu1(method, o, a);
+    return method == POISMF_PG ? pmf_launch_one_tu3(method, o, a) : method == POISMF_CG ? pmf_launch_one_tu2(method, o, a) :
+           method == POISMF_EVAL ? pmf_launch_one_tu4(method, o, a) : pmf_launch_one_tu1(method, o, a);
 }
 
 #define PMF_EW _Pragma("unroll") for (int i = 0; i < NC; i++)
@@ -868,6 +869,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     const real_t* F = which ? s->dB : s->dA;
     const size_t dimF = which ? s->dimB : s->dimA;
     const bool is_pg = p->method == POISMF_PG;
+    const int pm = p->method == POISMF_EVAL ? POISMF_CG : p->method;   // the evaluation-only kernels (plan.hpp, K_EVAL) are planned like CG
     const bool weighted = p->w_mult != (real_t)1.;
     if (seg >= (int)h.segs.size()) return 1;
     const bool prologue = seg <= 0;
@@ -953,12 +955,12 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // two slots per lane: single-wave rows only, and TNC's ~21 k-vectors leave room for 112 nonzeros of tile
     const bool regw_ok = reg_ok && (reg_ns == 1 || REG_G == 8);
     // (kernel-resource-usage: CG with 40 steps of two slots spills 360 bytes per lane even at one wave per SIMD, 36 steps 60)
-    const unsigned reg_max = reg_ns == 2 && REG_G == 16 ? (p->method == POISMF_TNCG ? 112u : p->method == POISMF_CG ? 144u : reg_nnz_max(p->method))
-                                                        : reg_nnz_max(p->method);
+    const unsigned reg_max = reg_ns == 2 && REG_G == 16 ? (pm == POISMF_TNCG ? 112u : pm == POISMF_CG ? 144u : reg_nnz_max(pm))
+                                                        : reg_nnz_max(pm);
     // teams: CG on doubles with two slots per lane (k = 50 fp64: 25 slots), rows handed out through the queue
     static const bool no_team = getenv("POISMF_HIP_NO_TEAM") != nullptr;  // testing knob
     static const bool static_rows_ = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;
-    const bool team_ok = !no_team && !static_rows_ && reg_ok && reg_ns == 2 && REG_G == 16 && sizeof(real_t) == 8 && p->method == POISMF_CG;
+    const bool team_ok = !no_team && !static_rows_ && reg_ok && reg_ns == 2 && REG_G == 16 && sizeof(real_t) == 8 && pm == POISMF_CG;
     // lane-per-nonzero engine (lane_eval.hpp): doubles with 25 / 50 slots per factor row, CG and TNCG; 24-bit row ids and
     // row strides, 32-bit byte offsets into the factor (as the register engine)
     static const bool no_lane = getenv("POISMF_HIP_NO_LANE") != nullptr;  // testing knob
@@ -971,10 +973,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     for (size_t j = 0; j < h.segs.size(); j++)
         if (seg < 0 || (size_t)seg == j) bins.insert(bins.end(), h.segs[j].bins.begin(), h.segs[j].bins.end());
     for (const Bin& b : bins) {
-        TileGeom g = plan_geom(s->k, b.cls, single_pass, p->method == POISMF_CG && p->limit_step);
+        TileGeom g = plan_geom(s->k, b.cls, single_pass, pm == POISMF_CG && p->limit_step);
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
         if (lane_ok) {
-            const LaneShape ls = lane_shape_for(b.cls, g.s_load, p->method);
+            const LaneShape ls = lane_shape_for(b.cls, g.s_load, pm);
             if (ls.waves > 0) {
                 if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp &&
                     launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)
@@ -992,7 +994,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             // (TNC keeps the tile size its length class names: in fp32 its results move in the last bits with the size of
             // the instance -- 62 of 900 rows in tests/test_gpu_parity.py's segment test -- and a row must not depend on
             // which other rows share its shard; PG and CG are bit-identical across instances and may ride along)
-            const bool ride = p->method != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
+            const bool ride = pm != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
             const int S = reg_steps_for(ride ? b.max_nnz : b.cls);
             if (!launches.empty() && launches.back().lane_L == 0 && launches.back().nw == 1 && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || (ride && b.count < 4096u)) && launches.back().begin + launches.back().count == b.begin)
@@ -1001,10 +1003,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 launches.push_back({ b.begin, b.count, g, 1, S, 0, b.nnz });
             continue;
         }
-        if (regw_ok && b.cls <= regw_nnz_max(p->method)) {
+        if (regw_ok && b.cls <= regw_nnz_max(pm)) {
             // medium rows: 2, 4 or 8 waves share a row, each keeps its part of the tile in registers
-            const int nw = regw_waves_for(b.cls, p->method);
-            const bool ride = p->method != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
+            const int nw = regw_waves_for(b.cls, pm);
+            const bool ride = pm != POISMF_TNCG || sizeof(real_t) == 8;   // (fp64 TNC is bit-identical across instances too)
             const int S = regw_steps_for(ride ? b.max_nnz : b.cls, nw);
             if (!launches.empty() && launches.back().lane_L == 0 && launches.back().nw == nw && launches.back().reg_S >= S &&
                 (launches.back().reg_S == S || (ride && b.count < 2048u)) && launches.back().begin + launches.back().count == b.begin)
@@ -1076,7 +1078,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         char lname[160];
         {
             char txt[192];
-            const char* m = is_pg ? "pg" : p->method == POISMF_CG ? "cg" : "tncg";
+            const char* m = is_pg ? "pg" : p->method == POISMF_EVAL ? "eval" : pm == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
             if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.count);
             else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
@@ -1627,6 +1629,23 @@ int factors_multiple(real_t* A, real_t* B, real_t* Bsum, real_t* Amean, real_t* 
     (void)nthreads;
     return factors_multiple_impl(A, B, Bsum, Amean, Xr, Xr_indptr, Xr_indices, k, dimA, l2_reg, w_mult, step_size, niter, maxupd, method,
                                  limit_step, reuse_mean, nullptr);
+}
+// Testing aid (G1): the device's own objective and gradient wrappers at a given point, row by row, through whatever engine a CG
+// half-sweep would use for rows of that length (plan.hpp, K_EVAL).  which = 0: fun_single + grad_single (ref: src/poismf.c:194-240);
+// 1: fun_and_grad (ref: :242-273).  G [dimA x k] gets the gradients, f [dimA] the function values; every row is evaluated at `point`.
+int poismf_hip_debug_row_eval(real_t* G, double* f, real_t* B, real_t* Bsum, real_t* point, real_t* Xr, sparse_ix* Xr_indptr,
+                              sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, int which)
+{
+    std::vector<unsigned> dec;
+    try { dec.assign(2 * dimA, 0u); } catch (const std::bad_alloc&) { return 1; }
+    const int rc = factors_multiple_impl(G, B, Bsum, point, Xr, Xr_indptr, Xr_indices, k, dimA, l2_reg, w_mult, (real_t)1e-7, 1, which ? 1 : 0,
+                                         POISMF_EVAL, true, true, dec.data());
+    if (rc) return rc;
+    for (size_t r = 0; r < dimA; r++) {
+        const unsigned long long b = ((unsigned long long)dec[2 * r + 1] << 32) | dec[2 * r];
+        memcpy(&f[r], &b, sizeof(double));
+    }
+    return 0;
 }
 // Testing aid: factors_multiple that also hands back every row's solver decisions (2 words per row, see
 // poismf_hip_session_decisions) -- how the golden single-row fixtures pin the device's iteration / evaluation counts.

@@ -189,3 +189,21 @@ def test_partial_lds_set_rows_repeat_bit_for_bit(method, maxupd):
                                           limit_step=True, reuse_mean=False, **kw) for _ in range(3)]
     assert np.isfinite(runs[0]).all() and runs[0].any()
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
+@pytest.mark.parametrize("method", ["cg", "pg"])
+def test_weighted_rows_on_both_sides_of_every_hand_over(prec, method):
+    """w_mult != 1: the row's constant term needs sum_j F_j over the row's nonzeros (adjustment_Bsum, ref: src/poismf.c:85-123), which
+    every engine takes from its on-chip tile -- one more thing that must hold on both sides of every hand-over.  (Round 3: the lane
+    instance with a partial LDS set counted that set's 16 rows four times here; poismf_hip_debug_row_eval's test found it.)"""
+    k = 50
+    csr, csc, A0, B0 = ragged_problem(BOUNDARY_LENGTHS, 4000, k, prec, seed=12)
+    kw = dict(w_mult=3.0)
+    if method == "pg":
+        kw.update(l2_reg=1e3, step_size=1e-9)
+    A, B, args = gpu_run(csr, csc, A0, B0, method, 2, k, **kw)
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
+    if method == "pg" and prec:
+        assert H.scaled_err(A, Ar) <= 1e-4 and H.scaled_err(B, Br) <= 1e-4
+    else:
+        compare(prec, method, csr, args, A, B, Ar, Br, converged=False)

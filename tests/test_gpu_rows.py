@@ -134,3 +134,57 @@ def test_g2_tnc_rows(rows, reuse):
             assert v <= 1e-6
         elif mf >= 75:
             assert v <= 1e-2
+
+
+# ---- G1: the objective / gradient wrappers themselves (poismf_hip_debug_row_eval) -----------------------------------------------------
+def _row_eval(F, bsum, point, xval, xind, w, l2, which):
+    """One row through the device's fun_single + grad_single (which = 0) or fun_and_grad (which = 1); `bsum` is the row's constant
+    term as the fixtures hand it to the reference (see _one_row for w != 1)."""
+    dt = F.dtype
+    if w != 1.0:
+        bsum = (bsum.astype(np.float64) - (w - 1.0) * F[xind.astype(np.int64)].astype(np.float64).sum(0)).astype(dt)
+    indptr = np.array([0, len(xval)], dtype=np.uint64)
+    f, G = api.debug_row_eval(np.ascontiguousarray(F), np.ascontiguousarray(bsum), np.ascontiguousarray(point), indptr, xind,
+                              np.ascontiguousarray(xval), l2, w, which)
+    return float(f[0]), G[0]
+
+
+def test_g1_fun_single_grad_single_fun_and_grad_vs_the_compiled_reference(rows):
+    """The golden rows' fun_single / grad_single / grad_single_w / fg_f / fg_g entries (minted from the compiled reference's
+    calc_fun_single, calc_grad_single[_w] and calc_fun_and_grad, ref: src/poismf.c:194-273) against the DEVICE's own wrappers of the
+    same names (solvers.hpp), evaluated by the row engine a CG half-sweep would pick for the row: k = 5 / 50 / 100, 1 .. 300
+    nonzeros, w = 1 and 10.  With w != 1 the device takes the weighted gradient (quirk Q11), with w = 1 the plain one."""
+    use_float, z = rows
+    tol_f, tol_g = (2e-6, 2e-5) if use_float else (1e-13, 1e-12)
+    worst_f = worst_g = 0.0
+    for ci in range(int(z["ncases"])):
+        p, F, a, bsum, xval, xind, w = _case(z, ci)
+        f0, g0 = _row_eval(F, bsum, a, xval, xind, w, float(z[p + "l2cg"]), 0)
+        f1, g1 = _row_eval(F, bsum, a, xval, xind, w, float(z[p + "l2tn"]), 1)
+        g_ref = z[p + ("grad_single_w" if w != 1.0 else "grad_single")].astype(np.float64)
+        for got, ref in ((f0, float(z[p + "fun_single"])), (f1, float(z[p + "fg_f"]))):
+            worst_f = max(worst_f, abs(got - ref) / max(abs(ref), 1e-300))
+        for got, ref in ((g0, g_ref), (g1, z[p + "fg_g"].astype(np.float64))):
+            worst_g = max(worst_g, float(np.max(np.abs(got.astype(np.float64) - ref)) / max(float(np.max(np.abs(ref))), 1e-300)))
+    print(f"G1 fun / grad wrappers {'f32' if use_float else 'f64'}: worst relative error of f {worst_f:.3g}, of g (scaled by max|g|) {worst_g:.3g}")
+    assert worst_f <= tol_f and worst_g <= tol_g
+
+
+@pytest.mark.parametrize("nnz", [40, 100, 200, 500, 1000, 1040, 1500, 3000])
+def test_g1_wrappers_on_every_engine_vs_checker(rows, nnz):
+    """The same wrappers on seeded k = 50 rows whose lengths walk through the engines of a CG half-sweep (register / lane instances with
+    one and several waves, the partial LDS set, teams of CUs, streamed tiles) against the checker's calc_* functions."""
+    use_float, _ = rows
+    F, a, bsum, xval, xind = H.random_row(50, nnz, 4000, use_float, seed=7 + nnz)
+    xind = np.ascontiguousarray(xind, dtype=np.uint64)
+    orc = H.checker(use_float, "cg")
+    tol_f, tol_g = (5e-6, 5e-5) if use_float else (1e-12, 1e-11)
+    for w in (1.0, 3.0):
+        f0, g0 = _row_eval(F, bsum, a, xval, xind, w, 1e4, 0)
+        f1, g1 = _row_eval(F, bsum, a, xval, xind, w, 1e3, 1)
+        rf0 = orc.calc_fun_single(a, F, bsum, xval, xind, 1e4, w)
+        rg0 = orc.calc_grad_single(a, F, bsum, xval, xind, 1e4, w, w != 1.0)
+        rf1, rg1 = orc.calc_fun_and_grad(a, F, bsum, xval, xind, 1e3, w)
+        assert abs(f0 - rf0) <= tol_f * abs(rf0) and abs(f1 - rf1) <= tol_f * abs(rf1), (w, f0, rf0, f1, rf1)
+        for got, ref in ((g0, rg0), (g1, rg1)):
+            assert np.max(np.abs(got.astype(np.float64) - ref.astype(np.float64))) <= tol_g * np.max(np.abs(ref)), w
