@@ -214,6 +214,8 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
 #define PMF_LANE_PG32X4 1   // rows of 513 .. 1024 nonzeros on FOUR waves of four sets each (three in registers, one in LDS), two such rows per CU
 #endif
             if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1 };
+            // (1025 .. 1152 nonzeros: 4.5 sets per wave do not fit; six waves x three sets, one row per CU, measured 2.50 ms against 1.85 ms
+            // for reg_eval.hpp's eight-wave kernel on the 21 k such rows of the C4 matrix -- they stay there)
             if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };
             if (PMF_LANE_PG32 && cls > 1024 && cls <= 1536) return { 3, 0, 0, 8, 1 };
             return { 0, 0, 0, 0, 0 };
