@@ -271,6 +271,8 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
 #else
     // (only in the instances with a compile-time slot count: the generic fp64 CG instance is at 512 registers already,
     // and the 14 slots in flight pushed it into scratch -- and into wrong results on the k = 200 test)
+    // (TNC: in the eight-wave long-row instances only -- a row of 1e5 nonzeros is ~800 chunks per evaluation, each a full trip to
+    // memory when nothing is requested ahead; the one-wave instances have no registers left for the 14 slots in flight)
     constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
 #endif
     RowEval<T, NC, SL, NW, PF> ev;
@@ -777,7 +779,12 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
         return rc;
     }
     if (o.nw > 1) {
-        switch (o.spl) {
+#ifndef PMF_LONG_SPECIAL
+#define PMF_LONG_SPECIAL 1   // the long-row path with the compile-time slot counts of the BASELINE configs too (and with them the prefetch of the next chunk)
+#endif
+        if (PMF_LONG_SPECIAL && !o.generic_only && o.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A, LONG_NW>(o.long_stream, method, a, o.lds, o.grid);
+        else if (PMF_LONG_SPECIAL && !o.generic_only && o.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B, LONG_NW>(o.long_stream, method, a, o.lds, o.grid);
+        else switch (o.spl) {
             case 1: rc = launch_method<1 * SLOT_ELEMS, 0, LONG_NW>(o.long_stream, method, a, o.lds, o.grid); break;
             case 2: rc = launch_method<2 * SLOT_ELEMS, 0, LONG_NW>(o.long_stream, method, a, o.lds, o.grid); break;
         }
