@@ -276,6 +276,9 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
     constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
 #endif
     RowEval<T, NC, SL, NW, PF> ev;
+    if constexpr (NW > 1) {
+        if (a.arrive != nullptr && threadIdx.x == 0) atomicAdd(a.arrive, 1u);
+    }
 #ifdef PMF_TIMING
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
 #endif

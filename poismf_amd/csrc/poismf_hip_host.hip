@@ -230,6 +230,7 @@ struct poismf_hip_session {
     unsigned* d_counter = nullptr;
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
+    unsigned* d_arrive = nullptr;           // workgroups of the forked long-row launch that have started (half_sweep_impl)
     unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far
     real_t* d_team_backup = nullptr;        // the rows a team launch starts from (restored before its re-run)
     size_t team_backup_elems = 0;
@@ -592,6 +593,7 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     if (pmf_alloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 16), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs)
+    if (pmf_alloc(&s->d_arrive, sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_team_err, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (cached_stream(device, &s->aux_stream)) return fail();
@@ -715,6 +717,7 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     pmf_free(s->d_queue, s->stream);
     pmf_free(s->d_team, s->stream);
     pmf_free(s->d_team_err, s->stream);
+    pmf_free(s->d_arrive, s->stream);
     pmf_free(s->d_team_backup, s->stream);
     (void)hipStreamSynchronize(s->stream);   // the stream-ordered frees have run
     if (aux) release_stream(s->device, aux);
@@ -1068,11 +1071,21 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     const bool forked = !no_fork && launches.size() > 1 && (any_long || fork_bins);
     hipStream_t long_stream = forked ? s->aux_stream : s->stream;
     double queued[2] = { 0.0, 0.0 };
+    // The long rows go to the second stream to run NEXT TO the other bins, not after them.  The other bins' kernels are persistent
+    // (a workgroup keeps its CU until the bin's queue is empty): whichever kernel reaches the chip first fills it, and on config C5
+    // that was the mid-length bin -- the 60 giant rows then waited 260 ms for a CU and ran on their own afterwards (390 ms for what
+    // takes 150 alone).  So every workgroup of the long-row launch counts itself in when it starts, and the main stream waits for
+    // that count (hipStreamWaitValue32: works on plain device memory here, scripts/probes/waitvalue_probe.hip) before it launches
+    // anything else.  Arrivals only ever grow, so a chip that cannot hold the whole launch at once delays the main stream, no more.
+    static const bool no_arrive = getenv("POISMF_HIP_NO_ARRIVE_WAIT") != nullptr;   // testing knob
+    const bool hold_back = forked && any_long && !no_arrive;
+    if (hold_back) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, sizeof(unsigned), s->stream));
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
         HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
     }
     int launch_no = 0;
+    unsigned arrive_goal = 0;
     if (prologue) s->last_plan[which].clear();
     for (const Launch& L : launches) {
         char lname[160];
@@ -1127,6 +1140,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                                M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, s->d_team_backup);
         }
         a.gate = nullptr;
+        const bool is_long = L.nw > 1 && L.reg_S == 0 && L.lane_L == 0;
+        a.arrive = hold_back && is_long ? s->d_arrive : nullptr;
         static const unsigned team_spin = getenv("POISMF_HIP_TEAM_SPIN_LIMIT") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_TEAM_SPIN_LIMIT"))) : TEAM_SPIN_LIMIT;   // testing knob
         a.team_spin = team_spin;
         unsigned grid_mult = one_wave_reg ? 32 : 2;
@@ -1154,6 +1169,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 HIP_TRY(hipEventRecord(lr.t0, lst));
             }
             rc = launch_one(p->method, o, a);
+            if (!rc && a.arrive != nullptr) {
+                arrive_goal += std::min<unsigned>(grid, (unsigned)s->num_cu);   // (one eight-wave workgroup per CU)
+                (void)hipStreamWaitValue32(s->stream, s->d_arrive, arrive_goal, hipStreamWaitValueGte, 0xffffffffu);   // (an error here only costs the overlap)
+            }
             if (!rc && L.team > 1) {
                 // if the team launch gave up: rows back to where they started, the same rows on the streamed LDS kernel, note it
                 hipLaunchKernelGGL(team_restore_rows_kernel, dim3((unsigned)std::min<size_t>(((size_t)L.count * s->k + 255) / 256, (size_t)s->num_cu * 8)),
@@ -1163,6 +1182,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 // (a.geom is the LDS engine's geometry for the launch's longest length class: what these rows take without teams)
                 af.team_buf = nullptr;
                 af.gate = s->d_team_err;
+                af.arrive = nullptr;
                 af.queue = s->d_queue + MAX_LAUNCHES + 8 + (launch_no % 8);
                 HIP_TRY(hipMemsetAsync(af.queue, 0, sizeof(unsigned), s->stream));
                 OneLaunch of = o;
