@@ -1148,7 +1148,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
         int rc = 1;
-        const int lane_stream = (forked && fork_bins && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
+        // (with long rows on the second stream, the one-wave bins that follow go wherever less work is queued: on C5 the lane rows
+        // run behind the giant rows on the second stream while the mid-length bin has the main one)
+        const int lane_stream = (forked && (fork_bins || any_long) && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
         hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
