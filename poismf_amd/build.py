@@ -117,9 +117,12 @@ def build(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and up_to_date():
             return lib_path(False), lib_path(True)
+        # (the hash of what is being built, taken BEFORE the compilers read it: a source edited while they run must not be
+        # recorded as built -- it was, once, and the next build() then skipped a stale library)
+        building = _source_hash()
         out = _build_locked(force, verbose)
         with open(STAMP, "w") as fh:
-            fh.write(_source_hash() + "\n")
+            fh.write(building + "\n")
         return out
 
 
