@@ -12,7 +12,11 @@ Workload (every N): the matrix BASELINE.json quotes the metric on -- uniform 1 0
 (seed 1; ~9.995e7 nonzeros after duplicate summing), k = 50 (configs C3 / C4).  The headline line is method = pg,
 fp32, the reference's Python defaults (l2 1e9, step 1e-7, maxupd 10); at N = 1 `extra` carries the other points of
 the metric on the SAME matrix, each with its own roofline block: pg with maxupd = 1 (the bandwidth point, R's
-default), pg with hyper-parameters that keep the factors finite (same work per sweep), and cg fp64 (config C3).
+default), pg with hyper-parameters that keep the factors finite (same work per sweep), cg and tncg fp32 (the solvers config
+C4's matrix is not quoted on, for completeness), cg fp64 (config C3) -- and `tncg_f64_c5`: config C5's own matrix (Last.FM-shaped
+358 858 x 160 112, power-law item degrees, k = 100, tncg fp64, l2 1e3, maxupd 1500), steady-state sweeps.  Every block carries the
+HBM roofline of SURVEY.md 8(d) AND a vector-ALU roofline (`roofline.valu`: the flops the reference's arithmetic needs for the
+decisions the solvers took, against the fp32 / fp64 vector peak) -- the multi-pass solvers are not HBM-bound.
 N > 1 is STRONG scaling of that one matrix: A rows and B rows are cut into per-rank ranges with balanced nonzero
 counts, every rank builds its CSR / CSC shards on its GPU from the triplets, both factors are replicated, and
 after each half the updated rows go to every peer over RCCL (poismf_amd/dist.py).
@@ -30,6 +34,9 @@ import sys
 import time
 
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")  # the CPU baseline threads over rows with OpenMP, as the reference does
+# the CPU baseline runs with its OpenMP threads bound (read by libgomp when it is loaded: before numpy / torch)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -48,6 +55,7 @@ WORKLOADS = {
     "C2": (10 ** 5, 10 ** 5, 10 ** 7),   # development only
 }
 K = 50
+C5_K, C5_MAXUPD, C5_L2 = 100, 1500, 1e3   # BASELINE config 5: tncg fp64, k = 100, maxupd = 15 k, l2 = the tncg default
 
 
 def algorithmic_bytes_half(nnz, dimM, k, s):
@@ -87,23 +95,24 @@ def timed_sweeps(alt, steps, device):
 class Job:
     """One session (one precision) on this rank's shards, reusable for several (method, hyper-parameter) runs."""
 
-    def __init__(self, trip, rangesA, rangesB, rank, device, use_float, segmentsA):
+    def __init__(self, trip, rangesA, rangesB, rank, device, use_float, segmentsA, k=K):
         self.trip, self.rangesA, self.rangesB, self.rank, self.device, self.use_float = trip, rangesA, rangesB, rank, device, use_float
         self.dimA, self.dimB = trip.shape
+        self.k = k
         t0 = time.perf_counter()
-        self.be = pdist.HipBackend(None, None, self.dimA, self.dimB, K, use_float,
+        self.be = pdist.HipBackend(None, None, self.dimA, self.dimB, k, use_float,
                                    dict(method="pg", l2_reg=1.0), rangesA[rank], rangesB[rank], device, coo=trip,
                                    segments=(1, segmentsA))
         torch.cuda.synchronize(device)
         self.setup_s = time.perf_counter() - t0
-        self.A0, self.B0 = harness.initialize_matrices(self.dimA, self.dimB, K, use_float, 1)
+        self.A0, self.B0 = harness.initialize_matrices(self.dimA, self.dimB, k, use_float, 1)
         self.nnz_local = (self.be.sess.nnz(0), self.be.sess.nnz(1))
 
     def run(self, method, maxupd, steps, warmup, l2=None, step0=1e-7, profile_steps=None):
         """warmup + `steps` timed sweeps with profiling OFF (the product configuration), then a separate profiled pass
         (HIP events around the row-kernel launches of each half, per-row pass counters) of `profile_steps` sweeps from
         the same starting point for the kernel time and the pass-weighted traffic."""
-        l2d, mu, _ = harness.auto_defaults(method, K)
+        l2d, mu, _ = harness.auto_defaults(method, self.k)
         l2 = l2d if l2 is None else l2
         maxupd = mu if maxupd is None else maxupd
         sess = self.be.sess
@@ -132,11 +141,12 @@ class Job:
             alt.sweep()
         k_ms = [sess.kernel_time(w) for w in (0, 1)]
         ev_stats = [sess.eval_stats(w) for w in (0, 1)]
+        dec_stats = [sess.decision_stats(w) for w in (0, 1)]   # (of the last profiled sweep)
         plan = [sess.plan(w) for w in (0, 1)]
         lprof = [sess.launch_profile(w) for w in (0, 1)]
         sess.profile(False)
         return dict(method=method, maxupd=maxupd, l2=l2, step0=step0, steps=steps, seconds=dt, finite=finite, alive=alive, psteps=psteps,
-                    kernel_ms=k_ms, ev_stats=ev_stats, plan=plan, lprof=lprof)
+                    kernel_ms=k_ms, ev_stats=ev_stats, dec_stats=dec_stats, plan=plan, lprof=lprof)
 
     def close(self):
         self.be.close()
@@ -148,6 +158,7 @@ def roofline_block(job, res, traffic_key=None):
     row-kernel durations (`kernel_ms_*`, `frac_row_kernels`, `launches`) come from a separate profiled pass: HIP events on the
     stream each launch is issued on, around every row-bin launch and around each half."""
     s = 4 if job.use_float else 8
+    K = job.k
     rA, rB = job.rangesA[job.rank], job.rangesB[job.rank]
     b_half = [algorithmic_bytes_half(job.nnz_local[0], rB[1] - rB[0], K, s), algorithmic_bytes_half(job.nnz_local[1], rA[1] - rA[0], K, s)]
     k_ms_half = [res["kernel_ms"][w][0] / res["psteps"] for w in (0, 1)]
@@ -159,13 +170,8 @@ def roofline_block(job, res, traffic_key=None):
     passes = res["ev_stats"][0][0] + res["ev_stats"][1][0]
     nnzp = res["ev_stats"][0][1] + res["ev_stats"][1][1]
     gb = nnzp * K * s / res["psteps"] / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if traffic_key and os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get(traffic_key)
-        except Exception:
-            traffic = None
+    traffic, traffic_source = traffic_from_profiles(traffic_key)
+    valu = valu_block(job, res, sweep_ms)
     # per launch: algorithmic bytes of the rows it covers / its average duration
     launches = []
     for w in (0, 1):
@@ -177,6 +183,7 @@ def roofline_block(job, res, traffic_key=None):
                              "calls": L["calls"], "algorithmic_bytes": int(by), "GBps": gbs, "frac": gbs / HBM_PEAK_GBS})
     dom = max(launches, key=lambda L: L["avg_ms"]) if launches else None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": traffic_source, "valu": valu,
             "sweep_ms_unprofiled": sweep_ms,
             "dominant_kernel": dom,
             "frac_row_kernels": achieved_k / HBM_PEAK_GBS,
@@ -189,7 +196,62 @@ def roofline_block(job, res, traffic_key=None):
                     "block); frac_row_kernels, kernel_ms_* and launches[] come from a separate profiled pass (HIP events on the stream "
                     "each launch is issued on; launches are serial, so their sum equals sum(Calls x AverageNs) of the half_sweep_* rows "
                     "of the rocprofv3 kernel stats under profiles/); dominant_kernel = the launch with the longest average duration; "
-                    "bytes = nnz*(4+s+k*s) + 2*dimM*k*s + (dimM+1)*8 per half; traffic = fabric-side bytes per sweep from separate PMC passes"}
+                    "bytes = nnz*(4+s+k*s) + 2*dimM*k*s + (dimM+1)*8 per half; traffic = fabric-side bytes per sweep from separate rocprofv3 "
+                    "--pmc passes of the same command (traffic_source says which committed file, and that its kernels are this tree's; "
+                    "null when the tree has changed since); valu = the second roofline: SURVEY.md 8(d)'s flop count against the vector peak"}
+
+
+VALU_PEAK_TFLOPS = {True: 157.3, False: 78.6}   # MI355X vector fp32 / fp64 (MI355X_MICROARCH.md); no MFMA on this path
+LOG_FLOPS = 25                                 # a log counted as ~25 flop-equivalents
+
+
+def valu_block(job, res, sweep_ms):
+    """The vector-ALU roofline of one run ("Flops"): the flops the REFERENCE's arithmetic needs for the decisions the
+    device's solvers took in the last profiled sweep -- a gradient (4k+1) per nonzero (ref src/poismf.c:126-133, :210-240), a
+    function value (2k+L) (ref :194-208), TNC's fused evaluation (4k+1+L) (ref :242-273) -- divided by the unprofiled sweep time
+    and by the vector peak of the precision.  The device does less than this where it prunes or caches line-search trials; the
+    numerator is the algorithm's work, as `achieved` is the algorithm's bytes."""
+    k = job.k
+    method = res["method"]
+    if method == "pg":
+        # every pass of every row is one gradient evaluation (ev_stats: sum over rows of passes x nonzeros, profiled sweeps)
+        nnzp = (res["ev_stats"][0][1] + res["ev_stats"][1][1]) / res["psteps"]
+        flops = nnzp * (4 * k + 1)
+        model = "sum_rows nnz x passes x (4k+1)"
+    elif method == "cg":
+        d = res["dec_stats"]
+        g = d[0]["nnz_iterations"] + d[1]["nnz_iterations"]                       # one gradient per iteration
+        f = g + d[0]["nnz_evaluations"] + d[1]["nnz_evaluations"]                 # f0 + failed trials (nfeval) + one accepted trial per iteration
+        flops = g * (4 * k + 1) + f * (2 * k + LOG_FLOPS)
+        model = "sum_rows nnz x (niter x (4k+1) + (nfeval + niter) x (2k+L)), L=25; niter / nfeval as minimize_nonneg_cg counts them"
+    else:
+        d = res["dec_stats"]
+        flops = (d[0]["nnz_evaluations"] + d[1]["nnz_evaluations"]) * (4 * k + 1 + LOG_FLOPS)
+        model = "sum_rows nnz x nfeval x (4k+1+L), L=25; nfeval as tnc counts fun_and_grad calls"
+    peak = VALU_PEAK_TFLOPS[bool(job.use_float)]
+    ach = flops / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
+    return {"bound": "valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "flops_per_sweep": flops, "model": model,
+            "note": "reference-equivalent flops of the last profiled sweep / unprofiled sweep time / vector peak (fp32 157.3, fp64 78.6 TFLOP/s)"}
+
+
+def traffic_from_profiles(key):
+    """(bytes per sweep, where it came from) -- the fabric-side traffic of the row kernels measured by separate rocprofv3 --pmc passes
+    (scripts/profile_round.sh) and committed under profiles/.  Only quoted when the file was recorded from THIS tree's kernels
+    (its source_hash equals poismf_amd.build's hash of the sources + flags); otherwise null, and the reason."""
+    tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not key or not os.path.exists(tf):
+        return None, None
+    try:
+        d = json.load(open(tf))
+    except Exception:
+        return None, "profiles/hbm_traffic.json unreadable"
+    if key not in d:
+        return None, f"profiles/hbm_traffic.json has no entry {key}"
+    have, want = d.get("source_hash"), build._source_hash()
+    if have != want:
+        return None, (f"profiles/hbm_traffic.json ({d.get('round', '?')}) was recorded from other kernel sources "
+                      f"(source_hash {str(have)[:12]} != this tree's {want[:12]}): not quoted")
+    return d[key], f"profiles/hbm_traffic.json@{d.get('round', '?')} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, source_hash {want[:12]} = this tree)"
 
 
 def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
@@ -198,65 +260,87 @@ def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
     l2, mu, _ = harness.auto_defaults(method, K)
     maxupd = mu if maxupd is None else maxupd
     A0, B0 = harness.initialize_matrices(dimA, dimB, K, use_float, 1)
-    t = {}
-    for numiter in (1, 1, 6):
+    t = {1: [], 6: []}
+    for numiter in (1, 1, 6, 1, 6, 1, 6):   # (the first call also pays device initialisation: dropped)
         A, B = A0.copy(), B0.copy()
         t0 = time.perf_counter()
         with np.errstate(all="ignore"):
             api._run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], A, B, method, True, l2, 0., 1., 1e-7, numiter, maxupd,
                             False, True, True, 1)
-        t[numiter] = (time.perf_counter() - t0) * 1e3
-    return {"abi_ms_first_iter": t[1], "abi_ms_per_extra_iter": (t[6] - t[1]) / 5.0,
+        t[numiter].append((time.perf_counter() - t0) * 1e3)
+    t1, t6 = min(t[1][1:]), min(t[6])
+    return {"abi_ms_first_iter": t1, "abi_ms_per_extra_iter": (t6 - t1) / 5.0, "abi_ms_six_iters": t6,
+            "samples_ms": {"numiter1": t[1][1:], "numiter6": t[6]},
             "note": f"run_poismf(method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}) on the workload matrix through "
-                    "ctypes, second call of the process (the first also pays device initialisation)"}
+                    "ctypes: min of 3 calls each with numiter 1 and 6 (the process's first call, which also pays device "
+                    "initialisation, is dropped); per_extra_iter = (min t6 - min t1) / 5"}
 
 
 _CPU_CACHE = {}
+_CPU_THREADS = {}   # the OpenMP thread count the CPU legs use, chosen once per process (cpu_baseline)
 
 
-def _cpu_inputs(trip, use_float):
-    """host CSR / CSC (size_t indices) for the reference's ABI + the starting factors, once per precision"""
-    if use_float not in _CPU_CACHE:
-        _CPU_CACHE.clear()   # one precision at a time: 2.4-3.2 GB each
+def _cpu_inputs(trip, use_float, k=K):
+    """host CSR / CSC (size_t indices) for the reference's ABI + the starting factors, once per (matrix, precision)"""
+    key = (id(trip), use_float)
+    if key not in _CPU_CACHE:
+        for old in [q for q in _CPU_CACHE if isinstance(q, tuple)]:
+            del _CPU_CACHE[old]   # one matrix and precision at a time: 2.4-3.2 GB each
         dimA, dimB = trip.shape
         csr, csc = api.coo_to_csr_csc(trip, use_float)
-        _CPU_CACHE[use_float] = (csr, csc, harness.initialize_matrices(dimA, dimB, K, use_float, 1))
-    return _CPU_CACHE[use_float]
+        _CPU_CACHE[key] = (csr, csc, harness.initialize_matrices(dimA, dimB, k, use_float, 1))
+    return _CPU_CACHE[key]
 
 
-def cpu_baseline(trip, method, use_float, maxupd, l2=None, step0=1e-7, iters=(1, 2)):
-    """The compiled reference (oracle/_ref) on this box's host cores, same matrix: steady-state seconds per sweep =
-    (t(n2 outer iterations) - t(n1 outer iterations)) / (n2 - n1), after a small warm-up call that spins up the OpenMP team.
-    `value` is None when the difference is not positive (noise wins).  ref loops timed: src/poismf.c:506-608 with
-    pg_iteration :139-188 / cg_iteration :275-322 + src/nonnegcg.c:177-346."""
-    from oracle import bindings
+def _physical_cores():
     try:
         import psutil
-        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+        return psutil.cpu_count(logical=False) or os.cpu_count()
     except Exception:
-        cores = os.cpu_count()
+        return os.cpu_count()
+
+
+def cpu_baseline(trip, method, use_float, maxupd, l2=None, step0=1e-7, iters=(1, 2), k=K, what="the whole workload matrix"):
+    """The compiled reference (oracle/_ref) on this box's host cores, same matrix: steady-state seconds per sweep =
+    (t(n2 outer iterations) - t(n1 outer iterations)) / (n2 - n1), after a small warm-up call that spins up the OpenMP team.
+    `value` is None when the difference is not positive (noise wins).  Threads are bound (OMP_PROC_BIND=close, OMP_PLACES=cores,
+    set at the top of this file); the first leg of a process runs its n1-iteration call with all physical cores and with half
+    of them and every leg then uses the faster count (`cores` = the threads used, `threads_tried` = both timings).
+    ref loops timed: src/poismf.c:506-608 with pg_iteration :139-188 / cg_iteration :275-322 + src/nonnegcg.c:177-346 /
+    tncg_iteration :324-404 + src/tnc.c:251-463."""
+    from oracle import bindings
+    phys = int(_physical_cores())
     kind = "reference" if bindings.ref_available(use_float) else "port"
     lib = bindings.Reference(use_float) if kind == "reference" else bindings.Oracle(use_float)
-    l2d, mu, _ = harness.auto_defaults(method, K)
+    l2d, mu, _ = harness.auto_defaults(method, k)
     l2 = l2d if l2 is None else l2
     maxupd = mu if maxupd is None else maxupd
-    csr, csc, (A0, B0) = _cpu_inputs(trip, use_float)
+    csr, csc, (A0, B0) = _cpu_inputs(trip, use_float, k)
 
-    def run(n, rows=None):
+    def run(n, threads):
         A, B = A0.copy(), B0.copy()
         t0 = time.perf_counter()
         with np.errstate(all="ignore"):
             lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], l2, 0.0, 1.0, step0, method, True, n, maxupd,
-                           False, True, True, cores)
+                           False, True, True, threads)
         return time.perf_counter() - t0
 
     if not _CPU_CACHE.get("warm"):
         # warm-up: a 1-iteration PG(1) call creates the OpenMP threads and touches the matrix once
         A, B = A0.copy(), B0.copy()
         with np.errstate(all="ignore"):
-            lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], 1e9, 0.0, 1.0, 1e-7, "pg", True, 1, 1, False, True, True, cores)
+            lib.run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], 1e9, 0.0, 1.0, 1e-7, "pg", True, 1, 1, False, True, True, phys)
         _CPU_CACHE["warm"] = True
-    times = [run(n) for n in iters]
+    if "threads" not in _CPU_THREADS:
+        tried = {n: run(iters[0], n) for n in sorted({phys, max(1, phys // 2)}, reverse=True)}
+        _CPU_THREADS["threads"] = min(tried, key=tried.get)
+        _CPU_THREADS["tried"] = {str(n): t for n, t in tried.items()}
+        _CPU_THREADS["tried_on"] = f"{iters[0]}-iteration run_poismf, method={method}, {'fp32' if use_float else 'fp64'}"
+        t_first = tried[_CPU_THREADS["threads"]]
+    else:
+        t_first = run(iters[0], _CPU_THREADS["threads"])
+    threads = _CPU_THREADS["threads"]
+    times = [t_first, run(iters[1], threads)]
     dt = (times[1] - times[0]) / (iters[1] - iters[0])
     nnz = len(csr[0])
     cpu = "unknown"
@@ -267,11 +351,14 @@ def cpu_baseline(trip, method, use_float, maxupd, l2=None, step0=1e-7, iters=(1,
                 break
     except OSError:
         pass
-    return {"value": nnz / dt if dt > 0 else None, "unit": "nnz/s per full sweep", "cores": int(cores), "kind": kind,
-            "seconds_per_sweep": dt if dt > 0 else None,
-            "sample": f"the whole workload matrix ({nnz} nnz), method={method}, maxupd={maxupd}, l2={l2:g}, step={step0:g}, "
+    return {"value": nnz / dt if dt > 0 else None, "unit": "nnz/s per full sweep", "cores": int(threads), "kind": kind,
+            "seconds_per_sweep": dt if dt > 0 else None, "physical_cores": phys,
+            "threads_tried": {"seconds": _CPU_THREADS["tried"], "on": _CPU_THREADS["tried_on"]},
+            "omp": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")},
+            "sample": f"{what} ({nnz} nnz), k={k}, method={method}, maxupd={maxupd}, l2={l2:g}, step={step0:g}, "
                       f"{'fp32' if use_float else 'fp64'}: run_poismf with {iters[1]} outer iterations ({times[1]:.2f} s) minus {iters[0]} "
-                      f"({times[0]:.2f} s) = {iters[1] - iters[0]} steady-state sweep(s), after a warm-up call, OpenMP threads={cores} on {cpu}"}
+                      f"({times[0]:.2f} s) = {iters[1] - iters[0]} steady-state sweep(s), after a warm-up call, OpenMP threads={threads} "
+                      f"(the faster of {sorted(int(n) for n in _CPU_THREADS['tried'])}, bound close to cores) on {cpu}"}
 
 
 def main():
@@ -316,9 +403,18 @@ def main():
         dimA, dimB, ntrip = dimA // f, dimB // f, ntrip // f
     use_float = not a.fp64
     t0 = time.perf_counter()
-    trip = synth.uniform_triplets(dimA, dimB, ntrip, seed=1)
+    if world == 1:
+        trip = synth.uniform_triplets(dimA, dimB, ntrip, seed=1)
+        rangesA, rangesB = plan_ranges(trip, world)
+    else:
+        # every rank needs the row / column counts of the WHOLE matrix (the ranges are cut at their quantiles), but only the triplets
+        # of its own ranges: the counts come from a chunked draw that keeps nothing, the triplets from a second, filtered draw of the
+        # same streams (synth.uniform_triplets_of: bit-identical to the rows / columns the one-shot draw gives this rank)
+        cntA, cntB, states = synth.uniform_counts(dimA, dimB, ntrip, seed=1)
+        rangesA, rangesB = pdist.choose_ranges(cntA, world), pdist.choose_ranges(cntB, world)
+        trip = synth.uniform_triplets_of(dimA, dimB, ntrip, rangesA[rank], rangesB[rank], states, seed=1)
+        del cntA, cntB
     gen_s = time.perf_counter() - t0
-    rangesA, rangesB = plan_ranges(trip, world)
     segA = a.segments if a.segments is not None else (4 if world > 1 else 1)
     job = Job(trip, rangesA, rangesB, rank, device, use_float, segA)
     res = job.run(a.method, a.maxupd, a.steps, a.warmup)
@@ -334,22 +430,46 @@ def main():
     final_line = None
     single = world == 1
     extra = {}
+    c5 = None
     if single and not a.no_extra:
         # the other points of the metric, same matrix, same session where the precision matches
-        for name, method, uf, mu, st, kw in (("pg_maxupd1_f32", "pg", True, 1, 10, {}),
-                                             ("pg_maxupd10_f32_finite", "pg", True, 10, 5, dict(l2=1e3, step0=1e-9)),
-                                             ("cg_f64", "cg", False, None, 3, {})):
+        # (name, method, fp32?, maxupd, timed sweeps, warm-up sweeps, overrides): TNCG's first sweeps from the random start cost a
+        # multiple of the later ones -- two warm-up sweeps, so that the timed ones are steady state
+        for name, method, uf, mu, st, wu, kw in (("pg_maxupd1_f32", "pg", True, 1, 10, 1, {}),
+                                                 ("pg_maxupd10_f32_finite", "pg", True, 10, 5, 1, dict(l2=1e3, step0=1e-9)),
+                                                 ("cg_f32", "cg", True, None, 3, 1, {}),
+                                                 ("tncg_f32", "tncg", True, None, 3, 2, {}),
+                                                 ("cg_f64", "cg", False, None, 3, 1, {})):
             if (name.startswith("pg") and a.method == "pg" and use_float and mu == res["maxupd"] and not kw):
                 continue
             j2 = job
             if uf != job.use_float:
                 job.close()
                 j2 = job = Job(trip, rangesA, rangesB, rank, device, uf, 1)
-            r = j2.run(method, mu, st, 1, **kw)
+            r = j2.run(method, mu, st, wu, **kw)
             extra[name] = {"value": j2.nnz_local[1] * st / r["seconds"], "unit": "nnz/s", "ms_per_step": r["seconds"] / st * 1e3,
                            "dtype": "f32" if uf else "f64", "method": method, "maxupd": r["maxupd"], "l2": r["l2"], "step": r["step0"],
-                           "steps": st, "finite": r["finite"], "alive": r["alive"],
+                           "steps": st, "warmup": wu, "finite": r["finite"], "alive": r["alive"],
                            "roofline": roofline_block(j2, r, f"{a.workload}_{method}_maxupd{r['maxupd']}_{'f32' if uf else 'f64'}")}
+        if a.workload == "C4" and not os.environ.get("POISMF_BENCH_SCALE"):
+            # BASELINE config C5 on ITS matrix ("and TNCG for C5"): Last.FM-shaped, power-law item degrees up to 1.4e5,
+            # k = 100, tncg fp64, l2 1e3, maxupd 1500 = 15 k, rows start from the previous sweep's (reuse_prev); steady-state sweeps
+            job.close()
+            t0 = time.perf_counter()
+            c5 = synth.lastfm_like_coo()
+            c5_gen_s = time.perf_counter() - t0
+            d5A, d5B = c5.shape
+            job = j5 = Job(c5, [(0, d5A)], [(0, d5B)], 0, device, False, 1, k=C5_K)
+            st, wu = 3, 2
+            r = j5.run("tncg", C5_MAXUPD, st, wu, l2=C5_L2)
+            extra["tncg_f64_c5"] = {"value": j5.nnz_local[1] * st / r["seconds"], "unit": "nnz/s", "ms_per_step": r["seconds"] / st * 1e3,
+                                    "dtype": "f64", "method": "tncg", "maxupd": r["maxupd"], "l2": r["l2"], "steps": st, "warmup": wu,
+                                    "finite": r["finite"], "alive": r["alive"],
+                                    "config": {"workload": f"C5: Last.FM-shaped {d5A}x{d5B}, {j5.nnz_local[1]} nnz (per-user degree 1+Poisson(47), items "
+                                                           f"~ (j+1)^-0.7, values 1+floor(LogNormal(4,1.3)), seed 1), k={C5_K}, method=tncg, fp64, "
+                                                           f"maxupd={C5_MAXUPD}, l2={C5_L2:g}, reuse_prev, no early stop",
+                                               "setup_s": {"triplets": c5_gen_s, "session_from_coo": j5.setup_s}},
+                                    "roofline": roofline_block(j5, r, f"C5_tncg_maxupd{r['maxupd']}_f64")}
     if rank == 0:
         sec = res["seconds"]
         out = {
@@ -374,13 +494,16 @@ def main():
         }
         if extra:
             out["extra"] = extra
-        # the three lines of the metric side by side in the parsed line: PG with the reference's defaults (the headline), PG with
-        # hyper-parameters that keep the factors alive (same work per sweep), CG fp64 (config C3) -- each with its roofline numbers
+        # the lines of the metric side by side in the parsed line: PG with the reference's defaults (the headline), PG with
+        # hyper-parameters that keep the factors alive (same work per sweep), CG / TNCG fp32, CG fp64 (config C3), TNCG fp64 on
+        # config C5's matrix -- each with its two roofline fractions
         head_name = f"{a.method}_maxupd{res['maxupd']}_{prec}_defaults"
         byc = {head_name: {"value": out["value"], "ms_per_step": out["ms_per_step"], "frac": headline_roofline["frac"],
+                           "frac_valu": headline_roofline["valu"]["frac"],
                            "frac_row_kernels": headline_roofline["frac_row_kernels"], "dominant_kernel": headline_roofline["dominant_kernel"]}}
         for name, blk in extra.items():
             byc[name] = {"value": blk["value"], "ms_per_step": blk["ms_per_step"], "frac": blk["roofline"]["frac"],
+                         "frac_valu": blk["roofline"]["valu"]["frac"],
                          "frac_row_kernels": blk["roofline"]["frac_row_kernels"], "dominant_kernel": blk["roofline"]["dominant_kernel"]}
         out["roofline"]["by_config"] = byc
         final_line = out
@@ -393,11 +516,15 @@ def main():
         del csr, csc
         byc_cpu = {head_name: {k_: cb[k_] for k_ in ("value", "seconds_per_sweep", "cores", "kind")}}
         if not a.no_extra:
-            # the other two lines of the metric get their CPU number too (fp32 inputs are still cached for the first)
-            for name, method, uf, kw in (("pg_maxupd10_f32_finite", "pg", True, dict(l2=1e3, step0=1e-9)), ("cg_f64", "cg", False, {})):
-                if name not in final_line.get("extra", {}):
+            # the other lines of the metric get their CPU number too (fp32 inputs are still cached for the first); cg / tncg fp32 on
+            # the C4 matrix are not lines of the metric and have none (a TNCG fp32 sweep of 1e8 nonzeros is minutes of CPU time)
+            for name, tr, method, uf, mu, kw in (("pg_maxupd10_f32_finite", trip, "pg", True, None, dict(l2=1e3, step0=1e-9)),
+                                                 ("cg_f64", trip, "cg", False, None, {}),
+                                                 ("tncg_f64_c5", c5, "tncg", False, C5_MAXUPD,
+                                                  dict(l2=C5_L2, k=C5_K, what="config C5's whole matrix"))):
+                if name not in final_line.get("extra", {}) or tr is None:
                     continue
-                c2 = cpu_baseline(trip, method, uf, None, **kw)
+                c2 = cpu_baseline(tr, method, uf, mu, **kw)
                 final_line["extra"][name]["cpu_baseline"] = c2
                 byc_cpu[name] = {k_: c2[k_] for k_ in ("value", "seconds_per_sweep", "cores", "kind")}
         final_line["cpu_baseline"]["by_config"] = byc_cpu

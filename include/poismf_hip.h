@@ -267,6 +267,11 @@ POISMF_HIP_API size_t poismf_hip_session_launch_profile(poismf_hip_session *s, i
  * minimize_nonneg_cg (niter, nfeval; ref src/nonnegcg.c:177-189) and tnc (nfeval, niter, rc; ref src/tnc.c:251-260) return and
  * cg_iteration / tncg_iteration discard.  Testing aid: pins the solvers' decisions, not only their results. */
 POISMF_HIP_API int poismf_hip_session_decisions(poismf_hip_session *s, int which, unsigned *out, size_t nrows);
+/* The same, summed over the rows of the shard: out[0] = sum of iterations, out[1] = sum of evaluations, out[2] = sum of
+ * nnz x iterations, out[3] = sum of nnz x evaluations -- what a flop count of the reference's arithmetic for the same decisions
+ * needs (a gradient is 4k+1 flops per nonzero, a function value 2k+L; ref src/poismf.c:126-133, :194-208).
+ * Returns 1 when the session is not profiling. */
+POISMF_HIP_API int poismf_hip_session_decision_stats(poismf_hip_session *s, int which, unsigned long long *out);
 /* factors_multiple (below / ref src/pred.c:66-199) that also returns those two words per row. */
 POISMF_HIP_API int poismf_hip_factors_multiple_decisions(real_t *A, real_t *B, real_t *Bsum, real_t *Amean, real_t *Xr,
                           sparse_ix *Xr_indptr, sparse_ix *Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult,

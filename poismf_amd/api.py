@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_nnz", "poismf_hip_selftest_log", "poismf_hip_session_eval_stats",
     "poismf_hip_session_create_coo", "poismf_hip_session_stream", "poismf_hip_session_factors_dirty", "poismf_hip_session_run",
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
-    "poismf_hip_session_launch_profile", "poismf_hip_session_decisions", "poismf_hip_factors_multiple_decisions",
+    "poismf_hip_session_launch_profile", "poismf_hip_session_decisions", "poismf_hip_session_decision_stats", "poismf_hip_factors_multiple_decisions",
     "poismf_hip_session_predict", "poismf_hip_session_topn", "poismf_hip_debug_row_eval",
 )
 
@@ -70,6 +70,8 @@ def load_library(use_float):
     lib.poismf_hip_factors_multiple_decisions.restype = i
     lib.poismf_hip_session_decisions.argtypes = [vp, i, vp, sz]
     lib.poismf_hip_session_decisions.restype = i
+    lib.poismf_hip_session_decision_stats.argtypes = [vp, i, C.POINTER(C.c_ulonglong)]
+    lib.poismf_hip_session_decision_stats.restype = i
     lib.predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
     lib.predict_multiple.restype = None
     lib.topN.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz, i]
@@ -531,6 +533,14 @@ class Session:
         if self.lib.poismf_hip_session_decisions(self.h, int(which), _ptr(dec), hi - lo):
             raise RuntimeError("poismf_hip_session_decisions: profiling is off")
         return (dec[:, 0] & 0xffffff).astype(np.int64), dec[:, 1].astype(np.int64), (dec[:, 0] >> 24).astype(np.int64)
+
+    def decision_stats(self, which):
+        """sums over this shard's rows of half `which` in the most recent half-sweep since profile(True):
+        dict(iterations, evaluations, nnz_iterations, nnz_evaluations)"""
+        out = (C.c_ulonglong * 4)()
+        if self.lib.poismf_hip_session_decision_stats(self.h, int(which), out):
+            raise RuntimeError("poismf_hip_session_decision_stats: profiling is off")
+        return dict(iterations=out[0], evaluations=out[1], nnz_iterations=out[2], nnz_evaluations=out[3])
 
     def nnz(self, which):
         return self.lib.poismf_hip_session_nnz(self.h, int(which))

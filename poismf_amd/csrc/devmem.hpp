@@ -61,8 +61,9 @@ inline hipError_t pmf_download(void* dst, const void* src, size_t bytes, hipStre
 // thread doing the copying; here a few host threads fill pinned chunks -- copying values, or NARROWING indices on the way, so that
 // half of the index bytes never cross PCIe -- while the DMA engine drains the chunks filled before (hipMemcpyAsync from pinned
 // memory, ~50 GB/s).  Each thread owns a contiguous part of the array and two chunks; an event per chunk says when it may be
-// refilled.  One staged upload at a time per process (the pool is shared); a caller that finds it busy -- the per-device threads
-// of a multi-GPU run -- takes the plain path.
+// refilled.  One pool PER DEVICE (round 4: the per-device threads of a multi-GPU run_poismf each stage through their own; with one
+// pool per process seven of eight set-ups fell back to the pageable path); one staged copy at a time per device, a caller that
+// finds its device's pool busy takes the plain path.
 struct PmfPinPool {
     static constexpr int THREADS_MAX = 16;
     static constexpr size_t CHUNK = (size_t)4 << 20;
@@ -70,18 +71,31 @@ struct PmfPinPool {
     void* buf[2 * THREADS_MAX] = {};
     hipEvent_t ev[2 * THREADS_MAX] = {};
     bool ready = false, failed = false;
-    int device = -1;   // events belong to the device they were created on: the pool serves that one only
-    bool prepare(int dev)
+    // (called with `busy` held and the device current: the events belong to that device)
+    bool prepare()
     {
-        if (ready || failed) return ready && dev == device;
-        device = dev;
-        for (int i = 0; i < 2 * THREADS_MAX; i++)
-            if (hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { failed = true; return false; }
+        if (ready || failed) return ready;
+        for (int i = 0; i < 2 * THREADS_MAX; i++) {
+            if (hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) != hipSuccess) buf[i] = nullptr;
+            if (buf[i] == nullptr || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+                // nothing half-built stays behind: this device copies through the plain path from now on
+                if (buf[i] != nullptr) { (void)hipHostFree(buf[i]); buf[i] = nullptr; }
+                for (int j = 0; j < i; j++) { (void)hipHostFree(buf[j]); buf[j] = nullptr; (void)hipEventDestroy(ev[j]); }
+                (void)hipGetLastError();
+                failed = true;
+                return false;
+            }
+        }
         ready = true;
         return true;
     }
 };
-inline PmfPinPool& pmf_pin_pool() { static PmfPinPool p; return p; }
+constexpr int PMF_PIN_POOL_DEVICES = 64;
+inline PmfPinPool* pmf_pin_pool(int device)
+{
+    static PmfPinPool pools[PMF_PIN_POOL_DEVICES];
+    return device >= 0 && device < PMF_PIN_POOL_DEVICES ? &pools[device] : nullptr;
+}
 inline int pmf_host_threads()
 {
     static const int n = [] {
@@ -105,9 +119,11 @@ inline bool pmf_staged_wanted(size_t bytes)
 template <class Fill> inline hipError_t pmf_upload_staged(void* dst, size_t n, size_t item, int device, hipStream_t stream, Fill&& fill)
 {
     if (!pmf_staged_wanted(n * item)) return hipErrorNotReady;
-    PmfPinPool& pool = pmf_pin_pool();
+    PmfPinPool* poolp = pmf_pin_pool(device);
+    if (poolp == nullptr) return hipErrorNotReady;
+    PmfPinPool& pool = *poolp;
     std::unique_lock<std::mutex> lk(pool.busy, std::try_to_lock);
-    if (!lk.owns_lock() || !pool.prepare(device)) return hipErrorNotReady;
+    if (!lk.owns_lock() || hipSetDevice(device) != hipSuccess || !pool.prepare()) return hipErrorNotReady;
     const int nt = pmf_host_threads();
     const size_t per_chunk = PmfPinPool::CHUNK / item;
     std::vector<hipError_t> err((size_t)nt, hipSuccess);
@@ -140,9 +156,11 @@ template <class Fill> inline hipError_t pmf_upload_staged(void* dst, size_t n, s
 template <class Take> inline hipError_t pmf_download_staged(const void* src, size_t n, size_t item, int device, hipStream_t stream, Take&& take)
 {
     if (!pmf_staged_wanted(n * item)) return hipErrorNotReady;
-    PmfPinPool& pool = pmf_pin_pool();
+    PmfPinPool* poolp = pmf_pin_pool(device);
+    if (poolp == nullptr) return hipErrorNotReady;
+    PmfPinPool& pool = *poolp;
     std::unique_lock<std::mutex> lk(pool.busy, std::try_to_lock);
-    if (!lk.owns_lock() || !pool.prepare(device)) return hipErrorNotReady;
+    if (!lk.owns_lock() || hipSetDevice(device) != hipSuccess || !pool.prepare()) return hipErrorNotReady;
     const int nt = pmf_host_threads();
     const size_t per_chunk = PmfPinPool::CHUNK / item;
     std::vector<hipError_t> err((size_t)nt, hipSuccess);

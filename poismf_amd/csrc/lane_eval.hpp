@@ -112,7 +112,11 @@ __device__ __forceinline__ unsigned acc_get(unsigned a)
 // LP_: a further, PARTIAL set of LP_ (16) nonzeros per wave in LDS (lanes >= LP_ of that set alias lanes < LP_ with a zero
 // coefficient), and the transposing reduction's scratch used in two halves -- what makes rows of 1025 .. 1088 nonzeros fit ONE
 // CU: 4 waves x (64 + 128 + 64 + 16) nonzeros, 155 KB of LDS.
-template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0> struct LaneEval {
+// NH_: row streams ("halves") per workgroup.  NH_ = 2: a workgroup of 2 NW_ waves works on TWO rows that are never in the same
+// phase -- while one half's NW_ waves run the solver's passes over their register tile, the other half's waves have their next
+// row's tile in flight and wait at the same barriers (sweep_rows_paired in poismf_hip.hip): the gather of one row always runs
+// under the solve of another, whatever the dispatcher and the row lengths do.  Each half has its own LDS block.
+template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0, int NH_ = 1> struct LaneEval {
     using SA = typename Slot<T>::A;
     static constexpr int SN = Slot<T>::N;                 // elements per 16-byte slot
     static constexpr int KP = KS * SN;                    // elements of a factor row, padded to whole slots
@@ -177,7 +181,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES) + AVEC_BYTES;
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
     static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) : 0;
-    static constexpr int SMEM_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;
+    static constexpr int NH = NH_;
+    static constexpr int HALF_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;   // one row stream's LDS block
+    static constexpr int SMEM_BYTES = NH * HALF_BYTES;
 #ifndef PMF_LANE_SPOINT
 #define PMF_LANE_SPOINT 1   // floats, all sets in registers: the point reaches the dots as SCALAR operands (set_point keeps it in a register,
                             // lane <-> dimension; eval() takes dimension c with one v_readlane and multiplies by the SGPR) instead of an LDS
@@ -215,6 +221,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     unsigned zero_row;
     int k, ldF;
     int lane, wid;
+    int half;            // NH_ > 1: which of the workgroup's row streams this wave belongs to
+    unsigned nbar;       // NH_ > 1: workgroup barriers this wave has passed since the row stream's driver last reset the count
     static constexpr int member = 0;
     struct ElemOf {   // factor dimension held in element i of this lane (only meaningful where act[i])
         int d0;
@@ -240,7 +248,16 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
         lane = lane_id();
-        wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
+        if constexpr (NH > 1) {   // (wave-uniform, and said so: the row stream's bookkeeping then lives in scalar registers)
+            const int wave = uniform((int)(threadIdx.x / WAVE));
+            wid = wave % NW;
+            half = wave / NW;
+        } else {
+            wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
+            half = 0;
+        }
+        nbar = 0;
+        smem += (size_t)half * HALF_BYTES;
         const int col = lane & 15, rr = lane >> 4;
         elem.d0 = col + CW * rr;
         const bool lane_on = col < CW && elem.d0 < DB;
@@ -766,6 +783,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             }
             if (lane == 0) xl[wid] = lsum;
             __syncthreads();
+            if constexpr (NH > 1) nbar++;
             double lp[NW];
 #pragma unroll
             for (int w = 0; w < NW; w++) lp[w] = xl[w];
@@ -794,6 +812,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     template <bool WANT_F, bool WANT_G, bool FROM_CACHE = false> __device__ __forceinline__ double eval(T sgn, T (&acc)[NC], T* store = nullptr)
     {
         n_eval++;
+        PMF_STAMP(*this, 0);
         T pred[LT];
         if constexpr (FROM_CACHE) {
 #pragma unroll
@@ -867,6 +886,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 pin_here();
             });
         }
+        PMF_STAMP(*this, 1);
         if (store == pbuf) {
 #pragma unroll
             for (int s = 0; s < LT; s++) pv[s] = pred[s];
@@ -885,6 +905,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         T tot[NC];
 #pragma unroll
         for (int i = 0; i < NC; i++) tot[i] = (T)0;
+        PMF_STAMP(*this, 2);
         if constexpr (WANT_G) {
             static_for<0, NC>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
@@ -892,12 +913,14 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 tot[b] = act[b] ? r : (T)0;
             });
         }
+        PMF_STAMP(*this, 3);
         if constexpr (NW > 1 && !WANT_F && !WANT_G) {
             return 0.0;
         } else if constexpr (NW > 1) {
             double lsum = 0.0;
             if constexpr (WANT_F) lsum = wave_sum(lpart);
             combine_waves(tot, lsum, WANT_G);
+            PMF_STAMP(*this, 4);
             if constexpr (WANT_G) {
 #pragma unroll
                 for (int i = 0; i < NC; i++) acc[i] += tot[i];

@@ -64,6 +64,8 @@ template <class T> struct HalfArgs {
     const unsigned* gate;             // != nullptr: the kernel runs only if *gate != 0 (the streamed re-run of a team launch that gave up)
     unsigned* arrive;                 // != nullptr (the long-row launch on the second stream): every workgroup counts itself in here when it
                                       // starts -- the main stream holds the other bins' kernels back until the long rows are on the chip
+    unsigned stagger;                 // != 0 (PG, several waves per row): a workgroup idles a pseudo-random number of shader cycles below this
+                                      // bound before its first row, so that the chip's CUs are not all gathering (or all computing) at once
 };
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1, K_EVAL = 4 };
@@ -180,7 +182,7 @@ inline TeamShape team_shape_for(unsigned max_nnz)
 // shortest rows) and of 13 slots in floats (k = 49..52).  Lane sets (64 nonzeros each) per wave -- in architectural registers,
 // in accumulator registers, in LDS -- and waves per row for rows of a length class; waves 0 = not a row of this engine.
 // A function of the class bound (and the solver) alone, so a row's arithmetic does not depend on its shard.
-struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; };   // small: a few KB of LDS per wave, two waves per SIMD; lp: nonzeros of a partial LDS set
+struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; int pair = 0; };   // pair: two row streams per workgroup (lane_eval.hpp, NH_ = 2)   // small: a few KB of LDS per wave, two waves per SIMD; lp: nonzeros of a partial LDS set
 #ifndef PMF_LANE_A2
 #define PMF_LANE_A2 0   // doubles, rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
                         // (measured, C3 A half, CG fp64: 22.3 ms against 20.0 -- the barrier per evaluation and the second copy of the
@@ -215,7 +217,12 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
 #ifndef PMF_LANE_PG32X4
 #define PMF_LANE_PG32X4 1   // rows of 513 .. 1024 nonzeros on FOUR waves of four sets each (three in registers, one in LDS), two such rows per CU
 #endif
-            if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1 };
+#ifndef PMF_LANE_PAIR
+#define PMF_LANE_PAIR 0   // (measured, C4 matrix: 7.05 ms against 4.86 -- a pass alone on its SIMD takes 4.8 k cycles, two of two rows side by side 5.1 k: the
+                          // passes are LATENCY-bound, and a second wave per SIMD that computes is worth more than one that gathers)
+                          // ... as TWO row streams per 8-wave workgroup: one stream's gather always runs under the other's passes (sweep_rows_paired)
+#endif
+            if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1, 0, PMF_LANE_PAIR };
             // (1025 .. 1152 nonzeros: 4.5 sets per wave do not fit; six waves x three sets, one row per CU, measured 2.50 ms against 1.85 ms
             // for reg_eval.hpp's eight-wave kernel on the 21 k such rows of the C4 matrix -- they stay there)
             if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };
@@ -252,6 +259,7 @@ struct OneLaunch {
     int team;                     // > 1: CUs per row (team launch)
     int lane_LP;                  // lane engine: nonzeros of the partial LDS set per wave
     int lane_small;               // lane engine: the two-waves-per-SIMD flavour (lane_eval.hpp, SMALL_)
+    int lane_pair;                // lane engine: two row streams per workgroup (lane_eval.hpp, NH_ = 2)
     int lane_L, lane_A, lane_LL;  // lane_L > 0: lane-per-nonzero engine with this many lane sets per wave in VGPRs, AGPRs, LDS (nw waves per row)
     bool generic_only;
     hipStream_t main_stream, bin_stream, long_stream;

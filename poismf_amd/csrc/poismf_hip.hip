@@ -135,6 +135,16 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
     T bs[NC];
     ev.load_vec(a.bsum, bs);
     const RowDesc* desc = a.desc + a.perm_begin;
+    if constexpr (METHOD == K_PG && NW > 1) {
+        // PG does the same work on every row, the rows of a launch are sorted by length and every workgroup starts at the same time:
+        // left alone the whole chip gathers at once (at the fabric's rate) and then computes at once (with the memory system idle).
+        // A different start delay per workgroup spreads the gathers over the compute phases of the others.
+        if (a.stagger != 0) {
+            const unsigned wait = (blockIdx.x * 2654435761u >> 8) % a.stagger;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while ((unsigned long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     if constexpr (EV::PIPELINED) {
         // Software pipeline over the rows of this wave.  A row costs three dependent round trips to memory -- its
@@ -254,6 +264,73 @@ __device__ __forceinline__ void sweep_rows_pf(const HalfArgs<T>& a, EV& ev, unsi
         t0 = t1; n0 = n1; l0 = l1; p0 = p1;
         t1 = t2; n1 = n2; l1 = l2; p1 = p2;
     }
+}
+
+// The row loop of the PAIRED lane-engine instances (lane_eval.hpp, NH_ = 2): a workgroup of 2 NW waves, two row streams.
+// Time is cut into phases; in every phase one half of the workgroup SOLVES the row whose tile sits in its registers while the
+// other half has the tile of ITS next row in flight, and the halves swap roles at the phase boundary.  What keeps them apart is
+// the workgroup barrier the solver's passes already contain (one per evaluation, LaneEval::combine_waves): the gathering waves
+// issue their loads and then simply arrive at the same NB barriers without waiting for memory in between (a bare s_barrier:
+// no fence, the loads stay in flight); their one wait for the tile is the first use of it in the next phase.  PG only -- NB is
+// known in advance (maxupd passes, + 1 for the column sums of a weighted row) -- with rows dealt out statically.
+// Why: two independent 4-wave workgroups per CU run the same deterministic program on rows of nearly equal length and stay in
+// lockstep, and so does the whole chip -- every CU gathers at once (fabric-bound), then every CU computes with the memory system
+// idle: PG(10) on the C4 matrix cost gather time PLUS pass time.  Here one stream's gather always runs under the other's passes.
+// Half h takes rows blockIdx.x + gridDim.x (2 i + h), i = 0, 1, ..: gathered in phase 2 i + h, solved in phase 2 i + h + 1.
+template <class EV, class T, int NC, int METHOD>
+__device__ __forceinline__ void sweep_rows_paired(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
+{
+    static_assert(METHOD == K_PG && EV::NH == 2 && EV::NW > 1, "two row streams of a solver with a fixed number of barriers per row");
+    if (a.gate != nullptr && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    ev.init(a.geom, a.F, smem);
+    T bs[NC];
+    ev.load_vec(a.bsum, bs);
+    const RowDesc* desc = a.desc + a.perm_begin;
+    const unsigned h = (unsigned)ev.half;
+    const unsigned first = blockIdx.x + gridDim.x * h, stride = 2u * gridDim.x;
+    // barriers per phase: what one solved row takes at most (every wave of the workgroup passes exactly this many per phase)
+    const unsigned NB = (unsigned)(a.P.maxupd > 0 ? a.P.maxupd : 0) + 1u;
+    // phases: stream 0 has the larger or equal number of rows n0; stream 1 ends one phase later when it has as many
+    const unsigned n0 = blockIdx.x < a.nrows ? (a.nrows - blockIdx.x - 1u) / stride + 1u : 0u;
+    const unsigned f1 = blockIdx.x + gridDim.x;
+    const unsigned n1 = f1 < a.nrows ? (a.nrows - f1 - 1u) / stride + 1u : 0u;
+    const unsigned phases = n1 == n0 && n1 > 0 ? 2u * n0 + 1u : 2u * n0;
+    auto fetch = [&](unsigned t) -> RowDesc { return desc[t < a.nrows ? t : 0u]; };   // (kept as loaded: no wait until a field is used)
+    auto start_of = [&](const RowDesc& d) { return ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo); };
+    // this stream's row being gathered / solved, and the one after it
+    unsigned t_cur = first;
+    RowDesc d_cur = fetch(t_cur), d_nxt = fetch(t_cur + stride);
+    for (unsigned p = 0; p < phases; p++) {
+        const bool gmode = ((p + h) & 1u) == 0u;
+        if (gmode) {
+            // my row's indices, then its tile -> registers: requested here, first used one phase later.  (The indices are NOT fetched
+            // a row ahead as sweep_rows does: both trips to memory lie under the other stream's solve anyway, and four more
+            // registers alive during the passes pushed the indices into scratch -- with a wait for the tile behind every reload.)
+            if (p >= h && t_cur < a.nrows) {
+                const unsigned nnz = uniform(d_cur.nnz);
+                if (nnz != 0) ev.begin_row(a.indices + start_of(d_cur), a.values + start_of(d_cur), nnz);
+            }
+            for (unsigned j = 0; j < NB; j++) asm volatile("s_barrier" ::: "memory");
+        } else {
+            ev.nbar = 0;
+            if (p > h && t_cur < a.nrows) {
+                const RowDesc d_new = fetch(t_cur + 2u * stride);   // (lands under the solve)
+                solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d_cur.lrow), uniform(d_cur.nnz));
+                t_cur += stride;
+                d_cur = d_nxt; d_nxt = d_new;
+            }
+            for (unsigned j = ev.nbar; j < NB; j++) asm volatile("s_barrier" ::: "memory");
+        }
+    }
+}
+
+template <class T, int METHOD, int KS, int LV, int NW>
+__global__ __launch_bounds__(WAVE* NW * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void half_sweep_lane_pair_kernel(const HalfArgs<T> a)
+{
+    using EV = LaneEval<T, KS, LV, 0, 0, NW, true, false, 0, 2>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
+    EV ev;
+    sweep_rows_paired<EV, T, EV::NC, METHOD>(a, ev, smem);
 }
 
 #ifndef PMF_TNC_PREFETCH
@@ -646,8 +723,25 @@ template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false
         return 0;
     } else return 1;
 }
-template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, int lp, const HalfArgs<real_t>& a, unsigned grid_mult)
+// paired instances (two row streams per workgroup, sweep_rows_paired): one workgroup of 2 NW waves per CU
+template <int METHOD, int KS, int LV, int NW> int launch_lane_pair(hipStream_t stream, const HalfArgs<real_t>& a)
 {
+    if constexpr (tu_has(METHOD) && METHOD == K_PG) {
+        auto kern = half_sweep_lane_pair_kernel<real_t, METHOD, KS, LV, NW>;
+        const unsigned grid = (unsigned)std::min<size_t>((a.nrows + 1) / 2, (size_t)t_num_cu);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW * 2), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    } else return 1;
+}
+template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, int lp, int pair, const HalfArgs<real_t>& a, unsigned grid_mult)
+{
+    if (pair) {
+        if constexpr (sizeof(real_t) == 4 && METHOD == K_PG) {
+            if (s_load == 13 && lv == 4 && la == 0 && ll == 0 && nw == 4 && lp == 0) return launch_lane_pair<METHOD, 13, 4, 4>(stream, a);
+        }
+        return 1;
+    }
     const int key = (((lv * 10 + la) * 10 + ll) * 10 + nw) * 10 + small + (lp > 0 ? 100000 : 0);
     if constexpr (sizeof(real_t) == 8) {
         if constexpr (METHOD == K_PG) return 1;
@@ -754,10 +848,10 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
     if (o.lane_L > 0) {
-        if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
-        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
-        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
-        if (method == POISMF_EVAL) return launch_lane_shape<K_EVAL>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, a, o.grid_mult);
+        if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
+        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
+        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
+        if (method == POISMF_EVAL) return launch_lane_shape<K_EVAL>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
         return 1;
     }
 #ifdef PMF_LANE_ONLY   // development: compile the lane-per-nonzero kernels alone (seconds instead of minutes)

@@ -7,11 +7,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <csignal>
 #include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -177,7 +179,8 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
 namespace {
 
 constexpr size_t LDS_RESIDENT_LIMIT = 64 * 1024;  // largest tile a single wave may claim
-constexpr int MAX_LAUNCHES = 64;  // row bins per half-sweep (16 fine classes + powers of two up to 2^31)
+constexpr int MAX_LAUNCHES = 256;  // launches per half-sweep call that get a row-queue head: length classes are multiples of 16 up to 256, of 64
+                                   // up to 2048, then powers of two (<= 60 per segment); a call over several segments concatenates their bins
 
 struct Bin {
     unsigned begin, count;  // range of the nnz-sorted permutation
@@ -231,6 +234,7 @@ struct poismf_hip_session {
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
     unsigned* d_arrive = nullptr;           // workgroups of the forked long-row launch that have started (half_sweep_impl)
+    bool no_hold_back = false;              // hipStreamWaitValue32 / WriteValue32 failed once: later half-sweeps launch without the hold-back
     unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far
     real_t* d_team_backup = nullptr;        // the rows a team launch starts from (restored before its re-run)
     size_t team_backup_elems = 0;
@@ -856,6 +860,28 @@ int poismf_hip_session_decisions(poismf_hip_session* s, int which, unsigned* out
     return 0;
 }
 
+// Sums over the rows of half `which` of what the solvers decided in the most recent half-sweep of a profiling session, for the
+// flop count the reference's arithmetic would need for the same decisions ("Flops"): out[0] = sum of iterations,
+// out[1] = sum of evaluations, out[2] = sum of nnz x iterations, out[3] = sum of nnz x evaluations.
+int poismf_hip_session_decision_stats(poismf_hip_session* s, int which, unsigned long long* out)
+{
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    Half& h = s->half[which ? 1 : 0];
+    const size_t n = h.row_end - h.row_begin;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (h.d_dec_rows == nullptr) return 1;
+    if (n == 0) return 0;
+    std::vector<unsigned> dec(2 * n);
+    std::vector<unsigned long long> ptr(n + 1);
+    HIP_TRY(hipMemcpy(dec.data(), h.d_dec_rows, 2 * sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ptr.data(), h.d_indptr, sizeof(unsigned long long) * (n + 1), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        const unsigned long long it = dec[2 * i] & 0xffffffu, ev = dec[2 * i + 1], nz = ptr[i + 1] - ptr[i];
+        out[0] += it; out[1] += ev; out[2] += nz * it; out[3] += nz * ev;
+    }
+    return 0;
+}
+
 // bsum_override != nullptr: use this HOST k-vector (already carrying l1 and any PG scaling) instead of the column
 // sums of the fixed factor; neg_step_override then replaces -step_size as the PG scale of the per-row Bsum_w.
 // seg < 0: every segment of the shard; seg >= 0: that segment only -- segment 0 then also runs the prologue (column sums,
@@ -929,7 +955,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     a.P.limit_step = p->limit_step;
     a.P.max_cg_it = (int)std::max(1.0, std::min(50.0, (double)(real_t)s->k / 2.0));  // ref: src/poismf.c:342
     static const bool no_prune = getenv("POISMF_HIP_NO_LS_PRUNE") != nullptr;  // testing knob: evaluate every line-search trial
-    a.P.x_pos = (h.x_positive && !no_prune) ? 1 : 0;
+    // (w_mult > 0: the bound that lets a line search skip a trial needs the data term -w sum x log(.) to be CONVEX along the line;
+    // the reference's Python wrapper asserts weight_mult > 0, the C ABI does not)
+    a.P.x_pos = (h.x_positive && !no_prune && p->w_mult > (real_t)0) ? 1 : 0;
     a.reuse_prev = p->reuse_prev;
     a.early_stop = (p->method == POISMF_TNCG) && p->early_stop && (n_unchanged != nullptr || seg >= 0);
     a.n_unchanged = s->d_counter;
@@ -947,7 +975,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
     // solver) are merged into one launch.
-    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0, lane_A = 0, lane_LL = 0, lane_small = 0, lane_LP = 0; };
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0, lane_A = 0, lane_LL = 0, lane_small = 0, lane_LP = 0, lane_pair = 0; };
     std::vector<Launch> launches;
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots (32 for doubles, two slots per lane), and 24-bit row ids / 32-bit
@@ -979,14 +1007,16 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         TileGeom g = plan_geom(s->k, b.cls, single_pass, pm == POISMF_CG && p->limit_step);
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
         if (lane_ok) {
-            const LaneShape ls = lane_shape_for(b.cls, g.s_load, pm);
+            LaneShape ls = lane_shape_for(b.cls, g.s_load, pm);
+            static const bool no_pair = getenv("POISMF_HIP_NO_PAIR") != nullptr;   // testing knob: one row stream per workgroup everywhere
+            if (no_pair) ls.pair = 0;
             if (ls.waves > 0) {
-                if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp &&
+                if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp && launches.back().lane_pair == ls.pair &&
                     launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)
                     { launches.back().count += b.count; launches.back().nnz += b.nnz; }
                 else {
                     launches.push_back({ b.begin, b.count, g, ls.waves, 0, 0, b.nnz });
-                    launches.back().lane_L = ls.lv; launches.back().lane_A = ls.la; launches.back().lane_LL = ls.ll; launches.back().lane_small = ls.small; launches.back().lane_LP = ls.lp;
+                    launches.back().lane_L = ls.lv; launches.back().lane_A = ls.la; launches.back().lane_LL = ls.ll; launches.back().lane_small = ls.small; launches.back().lane_LP = ls.lp; launches.back().lane_pair = ls.pair;
                 }
                 continue;
             }
@@ -1078,7 +1108,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // that count (hipStreamWaitValue32: works on plain device memory here, scripts/probes/waitvalue_probe.hip) before it launches
     // anything else.  Arrivals only ever grow, so a chip that cannot hold the whole launch at once delays the main stream, no more.
     static const bool no_arrive = getenv("POISMF_HIP_NO_ARRIVE_WAIT") != nullptr;   // testing knob
-    const bool hold_back = forked && any_long && !no_arrive;
+    // (s->no_hold_back: hipStreamWaitValue32 failed once on this runtime / device -- the launches then simply share the chip as they come)
+    const bool hold_back = forked && any_long && !no_arrive && !s->no_hold_back;
     if (hold_back) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, sizeof(unsigned), s->stream));
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
@@ -1093,7 +1124,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             char txt[192];
             const char* m = is_pg ? "pg" : p->method == POISMF_EVAL ? "eval" : pm == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
-            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.count);
+            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP ? "+16" : "", L.nw, L.lane_pair ? ",2/SIMD,paired" : L.lane_small ? ",2/SIMD" : "", L.count);
             else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
             else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
             else if (L.reg_S > 0) snprintf(txt, sizeof txt, "half_sweep_regw_kernel<%s,%s,S=%d,NW=%d> rows=%u;", t, m, L.reg_S, L.nw, L.count);
@@ -1140,6 +1171,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                                M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, s->d_team_backup);
         }
         a.gate = nullptr;
+        static const unsigned stagger = getenv("POISMF_HIP_STAGGER") ? (unsigned)std::max(0, atoi(getenv("POISMF_HIP_STAGGER"))) : 0u;   // tuning knob (shader cycles)
+        a.stagger = is_pg && L.nw > 1 ? stagger : 0u;
         const bool is_long = L.nw > 1 && L.reg_S == 0 && L.lane_L == 0;
         a.arrive = hold_back && is_long ? s->d_arrive : nullptr;
         static const unsigned team_spin = getenv("POISMF_HIP_TEAM_SPIN_LIMIT") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_TEAM_SPIN_LIMIT"))) : TEAM_SPIN_LIMIT;   // testing knob
@@ -1155,7 +1188,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
             OneLaunch o;
-            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.lane_A = L.lane_A; o.lane_LL = L.lane_LL; o.lane_small = L.lane_small; o.lane_LP = L.lane_LP; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
+            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.lane_A = L.lane_A; o.lane_LL = L.lane_LL; o.lane_small = L.lane_small; o.lane_LP = L.lane_LP; o.lane_pair = L.lane_pair; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
             static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
             o.generic_only = generic_only;
             o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
@@ -1173,7 +1206,17 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             rc = launch_one(p->method, o, a);
             if (!rc && a.arrive != nullptr) {
                 arrive_goal += std::min<unsigned>(grid, (unsigned)s->num_cu);   // (one eight-wave workgroup per CU)
-                (void)hipStreamWaitValue32(s->stream, s->d_arrive, arrive_goal, hipStreamWaitValueGte, 0xffffffffu);   // (an error here only costs the overlap)
+                // The way out of the wait below, whatever happens to the long-row launch: BEHIND it on its own stream the word is set to
+                // all ones, so the main stream is released at the latest when that launch has ended (it then ran before the other bins
+                // instead of beside them) -- no state of the chip leaves run_poismf waiting for workgroups that never arrive.
+                hipError_t we = hipStreamWriteValue32(long_stream, s->d_arrive, 0xffffffffu, 0);
+                if (we == hipSuccess) we = hipStreamWaitValue32(s->stream, s->d_arrive, arrive_goal, hipStreamWaitValueGte, 0xffffffffu);
+                if (we != hipSuccess) {
+                    // not supported here (or the stream is being captured): the error must not stay in the runtime's last-error slot
+                    // for the next launch's check to find, and the next half-sweeps do without the hold-back
+                    (void)hipGetLastError();
+                    s->no_hold_back = true;
+                }
             }
             if (!rc && L.team > 1) {
                 // if the team launch gave up: rows back to where they started, the same rows on the streamed LDS kernel, note it
@@ -1188,7 +1231,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 af.queue = s->d_queue + MAX_LAUNCHES + 8 + (launch_no % 8);
                 HIP_TRY(hipMemsetAsync(af.queue, 0, sizeof(unsigned), s->stream));
                 OneLaunch of = o;
-                of.reg_S = 0; of.nw = 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0; of.lane_LP = 0;
+                of.reg_S = 0; of.nw = 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0; of.lane_LP = 0; of.lane_pair = 0;
                 of.s_load = af.geom.s_load;
                 of.bin_stream = s->stream;
                 of.lds = lds_bytes_per_block(af.geom, sizeof(real_t), 1);
@@ -1453,95 +1496,192 @@ std::vector<Range> balanced_ranges(const sparse_ix* indptr, size_t n, size_t par
     return out;
 }
 
-template <class Fn> int on_every_device(size_t n, Fn&& fn)
-{
-    std::vector<int> rc(n, 0);
-    std::vector<std::thread> th;
-    for (size_t d = 1; d < n; d++) th.emplace_back([&, d]() { rc[d] = fn(d); });
-    rc[0] = fn(0);
-    for (auto& t : th) t.join();
-    for (int r : rc) if (r) return r;
-    return 0;
-}
+// Host threads meet here; the LAST one to arrive runs `last` (decisions every thread must share) before anybody leaves.
+struct HostBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t n, waiting = 0, generation = 0;
+    explicit HostBarrier(size_t n_) : n(n_) {}
+    template <class Fn> void arrive(Fn&& last)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const size_t gen = generation;
+        if (++waiting == n) {
+            last();
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+        } else cv.wait(lk, [&] { return generation != gen; });
+    }
+    void arrive() { arrive([] {}); }
+};
+
+// Round 4.  One PERSISTENT host thread per device runs the whole alternation for its device (round 3 created and joined a thread
+// per device twice per half and synchronised every stream with the host in between: at C4 on 8 GPUs a PG half is ~0.65 ms per
+// device, the same order as those).  Devices are ordered against each other by EVENTS only:
+//   * after a half, device d copies the rows it updated straight into every peer's replica (hipMemcpyPeerAsync, xGMI full mesh) on a
+//     COPY stream of its own, segment by segment (the A half is cut into segments, poismf_hip_session_set_segments): segment j
+//     travels while segment j + 1 computes; the event landed[d] is recorded behind the last copy;
+//   * before its next half, device d makes its session stream wait for landed[q] of every peer q.  That one wait covers all three
+//     hazards: the rows the next half gathers have arrived; a peer finished READING factor M (as the fixed factor of its previous
+//     half) before anybody's copies of M's new rows reach it (those copies follow kernels that waited for that peer's landed event);
+//     and d's own copies of two halves ago are done before d overwrites the same rows again (every peer waited for them before
+//     the half whose landed event d has just waited for).
+// A stream can only wait for an event that has been RECORDED, so the threads hand over "recorded" through an atomic counter per
+// device (a host-side spin for the record CALL of a peer, never for the device); two events per device alternate.
+// Host threads meet at a barrier once per outer iteration (interrupt flag and failures: everybody takes the same decision) and,
+// for TNCG with early stop, once per half (the unchanged-row counts are summed, ref: src/poismf.c:395-403).
+struct MultiRun {
+    size_t nd;
+    const std::vector<int>& devices;
+    std::vector<Range> rA, rB;
+    std::vector<poismf_hip_session*> ss;
+    std::vector<hipStream_t> copy_stream;
+    std::vector<hipEvent_t> seg_done;                  // "this segment's kernels are done": session stream -> copy stream
+    std::vector<hipEvent_t> landed;                    // [2 d + parity]: device d's rows of a half have reached every peer
+    std::unique_ptr<std::atomic<unsigned>[]> recorded; // halves of device d whose `landed` event has been recorded
+    std::vector<size_t> unchanged;
+    std::vector<hipError_t> err;
+    std::atomic<int> failed{0};
+    bool stop = false;                                 // decided at the iteration barrier
+    HostBarrier bar;
+    MultiRun(const std::vector<int>& devs, size_t dimA, size_t dimB, const sparse_ix* pA, const sparse_ix* pB)
+        : nd(devs.size()), devices(devs), rA(balanced_ranges(pA, dimA, devs.size())), rB(balanced_ranges(pB, dimB, devs.size())),
+          ss(nd, nullptr), copy_stream(nd, nullptr), seg_done(nd, nullptr), landed(2 * nd, nullptr),
+          recorded(new std::atomic<unsigned>[nd]), unchanged(nd, 0), err(nd, hipSuccess), bar(nd)
+    {
+        for (size_t d = 0; d < nd; d++) recorded[d].store(0);
+    }
+    void fail(size_t d)
+    {
+        if (err[d] == hipSuccess) err[d] = pmf_last_hip_error();
+        failed.store(1);
+    }
+    // every peer's rows of half number `h` (0-based) have been copied into THIS device's replica: ordered before whatever is
+    // issued next on the session stream
+    int wait_for_peers(size_t d, unsigned h)
+    {
+        for (size_t q = 0; q < nd; q++) {
+            if (q == d) continue;
+            while (recorded[q].load(std::memory_order_acquire) < h + 1) {
+                if (failed.load()) return 1;
+                std::this_thread::yield();
+            }
+            HIP_TRY(hipStreamWaitEvent(ss[d]->stream, landed[2 * q + (h & 1u)], 0));
+        }
+        return 0;
+    }
+};
 
 int run_poismf_multi(const std::vector<int>& devices, real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indices, real_t* B, real_t* Xc,
                      sparse_ix* Xc_indptr, sparse_ix* Xc_indices, size_t dimA, size_t dimB, size_t k, const poismf_hip_params& p, size_t numiter)
 {
-    const size_t nd = devices.size();
-    const std::vector<Range> rA = balanced_ranges(Xr_indptr, dimA, nd), rB = balanced_ranges(Xc_indptr, dimB, nd);
-    std::vector<poismf_hip_session*> ss(nd, nullptr);
-    std::vector<hipEvent_t> done(nd, nullptr);       // device d's rows of the half just run have reached every peer
-    auto cleanup = [&]() {
-        for (size_t d = 0; d < nd; d++) {
-            if (done[d]) { (void)hipSetDevice(devices[d]); (void)hipEventDestroy(done[d]); }
-            poismf_hip_session_destroy(ss[d]);
-        }
-    };
-    int rc = on_every_device(nd, [&](size_t d) -> int {
-        if (poismf_hip_session_create(&ss[d], devices[d], nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k,
-                                      rA[d].lo, rA[d].hi, rB[d].lo, rB[d].hi)) return 1;
-        if (poismf_hip_session_set_factors(ss[d], A, B)) return 1;
-        HIP_TRY(hipEventCreateWithFlags(&done[d], hipEventDisableTiming));
-        for (size_t q = 0; q < nd; q++)   // peer access where the pair allows it (the copies below work without, through the host)
+    MultiRun R(devices, dimA, dimB, Xr_indptr, Xc_indptr);
+    const size_t nd = R.nd;
+    const int method = p.method;
+    const bool tn_stop = (method == POISMF_TNCG) && p.early_stop;
+    int want_seg = 4;   // segments of the A half (the B shards are a tenth of the size: one)
+    if (const char* e = getenv("POISMF_HIP_MULTI_SEGMENTS")) want_seg = std::max(1, atoi(e));
+
+    auto setup = [&](size_t d) -> int {
+        if (poismf_hip_session_create(&R.ss[d], devices[d], nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k,
+                                      R.rA[d].lo, R.rA[d].hi, R.rB[d].lo, R.rB[d].hi)) return 1;
+        if (poismf_hip_session_set_factors(R.ss[d], A, B)) return 1;
+        HIP_TRY(hipSetDevice(devices[d]));
+        HIP_TRY(hipStreamCreateWithFlags(&R.copy_stream[d], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&R.seg_done[d], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&R.landed[2 * d], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&R.landed[2 * d + 1], hipEventDisableTiming));
+        if (want_seg > 1 && poismf_hip_session_set_segments(R.ss[d], 1, want_seg) < 0) return 1;
+        for (size_t q = 0; q < nd; q++)   // peer access where the pair allows it (the copies work without, staged by the runtime)
             if (devices[q] != devices[d]) { int can = 0; if (hipDeviceCanAccessPeer(&can, devices[d], devices[q]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[q], 0); }
         (void)hipGetLastError();
         return 0;
-    });
-    if (rc) { cleanup(); return 1; }
-
-    const int method = p.method;
-    real_t step_size = p.step_size;
-    const bool tn_stop = (method == POISMF_TNCG) && p.early_stop;
-    bool stopped_earlyA = false, stopped_earlyB = false;
-    // one half on every device, then the exchange: owner d sends rows [lo, hi) of the updated factor to every peer
-    auto half = [&](int which, real_t step, real_t cnst_div, size_t* unchanged_total) -> int {
-        const std::vector<Range>& rr = which ? rA : rB;
-        std::vector<size_t> unchanged(nd, 0);
-        int r = on_every_device(nd, [&](size_t d) -> int {
-            if (poismf_hip_half_sweep(ss[d], which, &p, step, cnst_div, tn_stop ? &unchanged[d] : nullptr)) return 1;
+    };
+    // one half on device d: its segments, each followed by the copies of its rows to every peer on the copy stream
+    auto half = [&](size_t d, int which, unsigned h, real_t step, real_t cnst_div) -> int {
+        poismf_hip_session* s = R.ss[d];
+        if (h > 0) {
+            if (R.wait_for_peers(d, h - 1)) return 1;
+            poismf_hip_session_factors_dirty(s, which ? 0 : 1);   // the fixed factor of this half received rows: its gather copy is re-derived
+        }
+        const int nseg = (int)s->half[which].segs.size();
+        R.unchanged[d] = 0;
+        for (int j = 0; j < nseg; j++) {
+            if (poismf_hip_half_sweep_segment(s, which, &p, step, cnst_div, j, tn_stop && j == nseg - 1 ? &R.unchanged[d] : nullptr)) return 1;
             HIP_TRY(hipSetDevice(devices[d]));
-            const size_t bytes = (rr[d].hi - rr[d].lo) * k * sizeof(real_t);
-            real_t* mine = (which ? ss[d]->dA : ss[d]->dB) + rr[d].lo * k;
+            size_t lo = 0, hi = 0;
+            if (poismf_hip_session_segment_rows(s, which, j, &lo, &hi)) return 1;
+            const size_t bytes = (hi - lo) * k * sizeof(real_t);
+            HIP_TRY(hipEventRecord(R.seg_done[d], s->stream));
+            HIP_TRY(hipStreamWaitEvent(R.copy_stream[d], R.seg_done[d], 0));
+            real_t* mine = (which ? s->dA : s->dB) + lo * k;
             for (size_t q = 0; q < nd && bytes > 0; q++) {
                 if (q == d) continue;
-                real_t* theirs = (which ? ss[q]->dA : ss[q]->dB) + rr[d].lo * k;
-                HIP_TRY(hipMemcpyPeerAsync(theirs, devices[q], mine, devices[d], bytes, ss[d]->stream));
+                real_t* theirs = (which ? R.ss[q]->dA : R.ss[q]->dB) + lo * k;
+                HIP_TRY(hipMemcpyPeerAsync(theirs, devices[q], mine, devices[d], bytes, R.copy_stream[d]));
             }
-            HIP_TRY(hipEventRecord(done[d], ss[d]->stream));
-            return 0;
-        });
-        if (r) return r;
-        // nobody reads the factor before every owner's rows have landed in its replica; the gather copies are re-derived
-        r = on_every_device(nd, [&](size_t d) -> int {
-            HIP_TRY(hipSetDevice(devices[d]));
-            for (size_t q = 0; q < nd; q++)
-                if (q != d) HIP_TRY(hipStreamWaitEvent(ss[d]->stream, done[q], 0));
-            if (nd > 1) poismf_hip_session_factors_dirty(ss[d], which);
-            HIP_TRY(hipStreamSynchronize(ss[d]->stream));
-            return 0;
-        });
-        if (unchanged_total) { *unchanged_total = 0; for (size_t u : unchanged) *unchanged_total += u; }
-        return r;
+        }
+        HIP_TRY(hipEventRecord(R.landed[2 * d + (h & 1u)], R.copy_stream[d]));
+        R.recorded[d].store(h + 1, std::memory_order_release);
+        return 0;
     };
-    for (size_t it = 0; it < numiter && !rc; it++) {
-        if (g_should_stop) break;
-        const real_t cnst_div = 1. / (1. + 2. * p.l2_reg * step_size);                      // quirk Q6
-        if (!(method == POISMF_TNCG && stopped_earlyB)) {                                   // B half first (quirk Q5)
-            size_t unchanged = 0;
-            rc = half(0, step_size, cnst_div, &unchanged);
-            if (tn_stop) stopped_earlyB = ((double)unchanged / (double)dimB) >= .95;        // ref: src/poismf.c:401-403
+    auto worker = [&](size_t d) {
+        pmf_last_hip_error() = hipSuccess;
+        if (setup(d)) R.fail(d);
+        R.bar.arrive();
+        real_t step_size = p.step_size;
+        bool stoppedA = false, stoppedB = false;
+        unsigned h = 0;
+        for (size_t it = 0; it < numiter; it++) {
+            R.bar.arrive([&] { R.stop = g_should_stop != 0 || R.failed.load() != 0; });
+            if (R.stop) break;
+            const real_t cnst_div = 1. / (1. + 2. * p.l2_reg * step_size);                       // quirk Q6
+            for (int which = 0; which < 2; which++) {                                           // B half first (quirk Q5)
+                bool& stopped = which ? stoppedA : stoppedB;
+                if (!(method == POISMF_TNCG && stopped)) {
+                    if (!R.failed.load() && half(d, which, h, step_size, cnst_div)) R.fail(d);
+                    h++;
+                    if (tn_stop) {                                                              // ref: src/poismf.c:395-403
+                        size_t total = 0;
+                        R.bar.arrive();
+                        for (size_t u : R.unchanged) total += u;
+                        R.bar.arrive();   // (everybody has read the counts before the next half resets them)
+                        stopped = ((double)total / (double)(which ? dimA : dimB)) >= .95;
+                    }
+                }
+                if (which == 0 && method == POISMF_PG) step_size *= 0.5;                        // ref: :532-533
+            }
+            if (stoppedA && stoppedB) break;
         }
-        if (method == POISMF_PG) step_size *= 0.5;                                          // ref: :532-533
-        if (rc || g_should_stop) break;
-        if (!(method == POISMF_TNCG && stopped_earlyA)) {
-            size_t unchanged = 0;
-            rc = half(1, step_size, cnst_div, &unchanged);
-            if (tn_stop) stopped_earlyA = ((double)unchanged / (double)dimA) >= .95;
+        // the last half's rows of every peer, then this device is done
+        if (!R.failed.load() && h > 0 && R.ss[d] != nullptr) {
+            if (R.wait_for_peers(d, h - 1)) R.fail(d);
+            else if (hipSetDevice(devices[d]) != hipSuccess || hipStreamSynchronize(R.ss[d]->stream) != hipSuccess ||
+                     hipStreamSynchronize(R.copy_stream[d]) != hipSuccess) { pmf_last_hip_error() = hipGetLastError(); R.fail(d); }
+            else if (team_check(R.ss[d])) R.fail(d);
         }
-        if (stopped_earlyA && stopped_earlyB) break;
+        R.bar.arrive();
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < nd; d++) th.emplace_back(worker, d);
+        worker(0);
+        for (auto& t : th) t.join();
     }
-    if (!rc) rc = poismf_hip_session_get_factors(ss[0], A, B);   // every replica holds the same bits
-    cleanup();
+    int rc = R.failed.load() ? 1 : 0;
+    if (rc) {   // the failing worker's error is what the caller reports (the workers' thread-local slots are gone)
+        pmf_last_hip_error() = hipSuccess;
+        for (hipError_t e : R.err) if (e != hipSuccess) { pmf_last_hip_error() = e; break; }
+    }
+    if (!rc) rc = poismf_hip_session_get_factors(R.ss[0], A, B);   // every replica holds the same bits
+    for (size_t d = 0; d < nd; d++) {
+        (void)hipSetDevice(devices[d]);
+        if (R.copy_stream[d]) { (void)hipStreamSynchronize(R.copy_stream[d]); (void)hipStreamDestroy(R.copy_stream[d]); }
+        if (R.seg_done[d]) (void)hipEventDestroy(R.seg_done[d]);
+        for (int e = 0; e < 2; e++) if (R.landed[2 * d + e]) (void)hipEventDestroy(R.landed[2 * d + e]);
+        poismf_hip_session_destroy(R.ss[d]);
+    }
     return rc ? 1 : 0;
 }
 
@@ -1682,6 +1822,7 @@ static int factors_multiple_impl(real_t* A, real_t* B, real_t* Bsum, real_t* Ame
                                  sparse_ix* Xr_indices, int k, size_t dimA, real_t l2_reg, real_t w_mult, real_t step_size,
                                  size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean, unsigned* decisions)
 {
+    pmf_last_hip_error() = hipSuccess;   // (what this call reports on failure is this call's error, not an earlier call's)
     const size_t ks = (size_t)k;
     const size_t nnz = Xr_indptr[dimA];
     // rows start at the mean of the fitted A, except TNCG without reuse_mean (1e-3, set in the kernel); ref: :144-147

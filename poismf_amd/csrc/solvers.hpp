@@ -113,6 +113,10 @@ __device__ __forceinline__ T fun_and_grad(EV& ev, const RowParams<T>& P, const T
 // an iteration takes from max_step <= 1 by factors of 4.  The last of the max_ls trials is always evaluated (quirk Q2 hands its
 // value on), and f_x is f at the current x even when f_cur is not (Q2 again).
 // Returns false when the evaluation budget runs out on the way (the reference returns from the row there, ref: :316-320).
+// Assumptions: x_j > 0 AND w > 0 (RowParams::x_pos: the host clears it for w <= 0, where the data term is not convex along the
+// line); and the trial point is x + s d up to the snap of components below 1e-15 to 0 (quirk Q10).  The snap can only RAISE the
+// data term (a prediction gets smaller, -w x_j log(.) larger) and moves the quadratic part by at most |Bsum_i + 2 l2 x_i| 1e-15 per
+// snapped coordinate, which the 1e-9 / 1e-3 relative margin covers: the bound stays a lower bound of the value the reference sees.
 template <class T>
 __device__ __forceinline__ bool skip_certain_failures(T f_x, T f_cur, T gd, T l2dd, T dd, T c_ls, T decr, int max_ls, int maxnfeval,
                                                       T& step, int& ls, int& nfeval)

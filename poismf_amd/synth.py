@@ -40,6 +40,48 @@ def uniform_triplets(dimA, dimB, nnz, seed=1):
     return Triplets(row, col, val, (dimA, dimB))
 
 
+def _chunks(n, step):
+    for lo in range(0, n, step):
+        yield lo, min(n, lo + step)
+
+
+def uniform_counts(dimA, dimB, nnz, seed=1, chunk=1 << 24):
+    """Triplets per row and per column of uniform_triplets(dimA, dimB, nnz, seed), without keeping the triplets: the row / column
+    streams are drawn chunk by chunk (same generator, same order, same values as the one-shot draw) and only counted.  Also returns the
+    generator states at the start of the column stream and of the value stream, so that uniform_triplets_of can re-draw the three
+    streams side by side."""
+    rng = np.random.default_rng(seed)
+    cntA, cntB = np.zeros(dimA, np.int64), np.zeros(dimB, np.int64)
+    for lo, hi in _chunks(nnz, chunk):
+        cntA += np.bincount(rng.integers(0, dimA, hi - lo, dtype=np.int64), minlength=dimA)
+    st_col = rng.bit_generator.state
+    for lo, hi in _chunks(nnz, chunk):
+        cntB += np.bincount(rng.integers(0, dimB, hi - lo, dtype=np.int64), minlength=dimB)
+    st_val = rng.bit_generator.state
+    return cntA, cntB, (st_col, st_val)
+
+
+def uniform_triplets_of(dimA, dimB, nnz, rowsA, rowsB, states, seed=1, chunk=1 << 24):
+    """The triplets of uniform_triplets(dimA, dimB, nnz, seed) whose row lies in rowsA = (lo, hi) OR whose column lies in rowsB: what a
+    rank that owns those row ranges of the two halves needs, and nothing else (one rank of eight keeps ~ 1/8 + 1/8 of the matrix instead
+    of generating and holding all of it).  `states` comes from uniform_counts.  Bit-identical values: the three streams are re-drawn in
+    lockstep from the generator states at which the one-shot draw starts each of them."""
+    gens = [np.random.default_rng(seed), np.random.default_rng(seed), np.random.default_rng(seed)]
+    gens[1].bit_generator.state = states[0]
+    gens[2].bit_generator.state = states[1]
+    keep_r, keep_c, keep_v = [], [], []
+    for lo, hi in _chunks(nnz, chunk):
+        r = gens[0].integers(0, dimA, hi - lo, dtype=np.int64)
+        c = gens[1].integers(0, dimB, hi - lo, dtype=np.int64)
+        v = gens[2].standard_gamma(1.0, hi - lo)
+        m = ((r >= rowsA[0]) & (r < rowsA[1])) | ((c >= rowsB[0]) & (c < rowsB[1]))
+        keep_r.append(r[m]); keep_c.append(c[m]); keep_v.append(v[m])
+    val = np.concatenate(keep_v)
+    np.floor(val, out=val)
+    val += 1.0
+    return Triplets(np.concatenate(keep_r), np.concatenate(keep_c), val, (dimA, dimB))
+
+
 def uniform_coo(dimA, dimB, nnz, seed=1):
     """The same triplets as a SciPy COO matrix."""
     t = uniform_triplets(dimA, dimB, nnz, seed)

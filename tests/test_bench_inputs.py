@@ -49,3 +49,22 @@ def test_segments_tile_a_range_like_the_session_does():
             assert all(segs[j][1] == segs[j + 1][0] for j in range(nseg - 1))
             n = rng[1] - rng[0]
             assert segs == [(rng[0] + n * j // nseg, rng[0] + n * (j + 1) // nseg) for j in range(nseg)]   # finish_half's cut
+
+
+def test_sharded_generation_reproduces_the_one_shot_triplets():
+    """bench.py --gpus N: a rank draws the row / column COUNTS of the whole matrix chunk by chunk (ranges are cut at their quantiles) and
+    then only the triplets of its own row ranges (synth.uniform_counts / uniform_triplets_of) -- the same values, in the same order,
+    as filtering the one-shot draw every rank used to make and hold."""
+    dimA, dimB, n = 1000, 300, 200000
+    t = synth.uniform_triplets(dimA, dimB, n, seed=1)
+    cA, cB, st = synth.uniform_counts(dimA, dimB, n, seed=1, chunk=7777)
+    assert np.array_equal(cA, np.bincount(t.row, minlength=dimA)) and np.array_equal(cB, np.bincount(t.col, minlength=dimB))
+    rA, rB = pdist.choose_ranges(cA, 3), pdist.choose_ranges(cB, 3)
+    assert (rA, rB) == _bench().plan_ranges(t, 3)
+    seen = np.zeros(n, bool)
+    for r in range(3):
+        u = synth.uniform_triplets_of(dimA, dimB, n, rA[r], rB[r], st, seed=1, chunk=5000)
+        m = ((t.row >= rA[r][0]) & (t.row < rA[r][1])) | ((t.col >= rB[r][0]) & (t.col < rB[r][1]))
+        assert np.array_equal(u.row, t.row[m]) and np.array_equal(u.col, t.col[m]) and np.array_equal(u.data, t.data[m])
+        seen |= m
+    assert seen.all()

@@ -124,3 +124,109 @@ def test_cg_decisions_on_a_matrix_vs_checker(prec):
         assert frac >= 0.99             # measured: 400 of 400
     else:
         assert frac >= 0.90 and np.mean(dn) <= 0.3   # fp32 (measured: 0.95 identical, mean |delta nfeval| 0.09): a backtracking step more or less
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The line-search prune AT ITS MARGIN (solvers.hpp, skip_certain_failures; ref of the loop it shortcuts: src/nonnegcg.c:297-327).
+# A trial step s is skipped when the tangent bound  lb = f(x) + s g.d + s^2 l2 d.d  exceeds the Armijo threshold  thr = f_cur -
+# c s d.d  by more than marg = eps_m (|f(x)| + |f_cur|).  The rows below are built so that, in the first iteration, the THIRD trial
+# (s = 1/16) has lb - thr anywhere from below 0 to several marg -- and, the log term being almost linear over such a step, the true
+# f(x + s d) lies within ~1.6 marg of lb: the function value the reference computes sits within a few eps_m of its threshold.
+#
+# Construction (all coordinates equal, so the k-dimensional row is k copies of a scalar problem): F rows = b 1, start a 1 with
+# k a b = 1, values summing to X = k x_eff, Bsum = beta 1:  g_i = beta + 2 l2 a - x_eff / a =: g < 0  =>  d = -g 1 > 0, max_step = 1,
+# trials s = 1, 1/4, 1/16, ..;  lb - thr = s k g^2 (l2 s - 0.99).  l2 = 16 (0.99 + eps) puts the tie of the BOUND at s = 1/16;
+# eps scans the margin.  g = -1e-3 (fp64) / -1 (fp32) sets the scale so that marg corresponds to eps ~ 0.55 in both precisions.
+# ------------------------------------------------------------------------------------------------------------------------------
+MARGIN_K = 50
+MARGIN_LENGTHS = [1, 40, 100, 200, 700, 1100]     # one row per length: register / lane engines, one and several waves per row
+MARGIN_EPS = [-0.30, -0.10, 0.0, 0.05, 0.10, 0.20, 0.30, 0.40, 0.50, 0.54, 0.58, 0.62, 0.70, 0.80, 1.0, 2.0]
+
+
+def _margin_problem(use_float, eps):
+    dt = np.float32 if use_float else np.float64
+    k, a, xeff = MARGIN_K, 1.0, 40.0
+    b = 1.0 / (k * a)
+    g = -1.0 if use_float else -1e-3
+    l2 = 16.0 * (0.99 + eps)
+    beta = g - 2.0 * l2 * a + xeff / a
+    dimB = max(MARGIN_LENGTHS) + 7
+    F = np.full((dimB, k), b, dtype=dt)
+    rng = np.random.default_rng(17)
+    vals, inds, ptr = [], [], [0]
+    for n in MARGIN_LENGTHS:
+        vals.append(np.full(n, k * xeff / n))
+        inds.append(np.sort(rng.choice(dimB, n, replace=False)))
+        ptr.append(ptr[-1] + n)
+    # host mirror of the third trial, in double: where the bound and the true value sit relative to the threshold, in units of marg
+    f0 = k * (beta * a + l2 * a * a)                      # (log(k a b) = 0)
+    eps_m = 1e-3 if use_float else 1e-9
+    marg = eps_m * 2.0 * abs(f0)
+    s = 1.0 / 16.0
+    dd = k * g * g
+    bound_gap = s * dd * (l2 * s - 0.99)                  # lb - thr
+    u = s * abs(g) / a
+    true_gap = bound_gap + k * xeff * (u - np.log1p(u))   # f(x + s d) - thr
+    return dict(F=F, bsum=np.full(k, beta, dtype=dt), start=np.full(k, a, dtype=dt), val=np.concatenate(vals).astype(dt),
+                ind=np.concatenate(inds).astype(np.uint64), ptr=np.array(ptr, dtype=np.uint64), l2=l2,
+                bound_over_marg=bound_gap / marg, true_over_marg=true_gap / marg)
+
+
+MARGIN_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from poismf_amd import api
+from tests.test_gpu_decisions import _margin_problem, MARGIN_EPS
+out = []
+for eps in MARGIN_EPS:
+    P = _margin_problem({use_float}, eps)
+    A, ni, nf, rc = api.factors_multiple_with_decisions(P["F"], P["bsum"], P["start"], P["ptr"], P["ind"], P["val"], l2_reg=P["l2"],
+                                                        step_size=1e-7, niter=1, maxupd={maxupd}, method="cg", limit_step=True, reuse_mean=True)
+    out.append(np.concatenate([A.ravel().astype(np.float64), ni, nf, rc]))
+np.save({out!r}, np.array(out))
+"""
+
+
+@pytest.mark.parametrize("prec", [False, True], ids=["f64", "f32"])
+@pytest.mark.parametrize("maxupd", [1, 5])
+def test_line_search_prune_at_its_margin(prec, maxupd, tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("prune", {}), ("all", {"POISMF_HIP_NO_LS_PRUNE": "1"})):
+        out = str(tmp_path / f"{tag}.npy")
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", MARGIN_CHILD.format(root=root, use_float=prec, maxupd=maxupd, out=out)], check=True, env=e,
+                       cwd=root, timeout=600)
+        res[tag] = np.load(out)
+    # 1. skipping never changes anything: same decisions, same bits, with every trial evaluated and with the certain failures skipped
+    assert np.array_equal(res["prune"], res["all"])
+    # 2. the scan really covers the margin: third-trial bounds below the threshold, inside (0, marg) and beyond marg, and true function
+    #    values within two marg of the threshold
+    info = [_margin_problem(prec, eps) for eps in MARGIN_EPS]
+    bo = np.array([p["bound_over_marg"] for p in info])
+    to = np.array([p["true_over_marg"] for p in info])
+    assert (bo < 0).any() and ((bo > 0) & (bo < 1)).sum() >= 3 and ((bo > 1) & (bo < 1.5)).any() and (bo > 3).any()
+    assert ((to > 0) & (to < 2.0)).any()
+    # 3. the reference's own decisions, row by row (its minimize_nonneg_cg through the checker)
+    orc = H.checker(prec, "cg")
+    nrow = len(MARGIN_LENGTHS)
+    same = total = 0
+    for p, got in zip(info, res["prune"]):
+        ni, nf, rc = (got[-3 * nrow:].reshape(3, nrow)).astype(np.int64)
+        ip = p["ptr"].astype(np.int64)
+        for r in range(nrow):
+            _, _, ni_r, nf_r, rc_r = orc.cg_row(p["start"], p["F"], p["bsum"], np.ascontiguousarray(p["val"][ip[r]:ip[r + 1]]),
+                                                np.ascontiguousarray(p["ind"][ip[r]:ip[r + 1]]), p["l2"], 1.0, maxupd, True)
+            total += 1
+            ok = (int(ni[r]), int(nf[r]), int(rc[r])) == (int(ni_r), int(nf_r), int(rc_r))
+            same += ok
+            if not ok:
+                print(f"   eps-case bound/marg {p['bound_over_marg']:.3g} nnz {MARGIN_LENGTHS[r]}: gpu ({ni[r]}, {nf[r]}, {rc[r]}) reference ({ni_r}, {nf_r}, {rc_r})")
+    print(f"prune margin {'f32' if prec else 'f64'} maxupd={maxupd}: {same} / {total} rows with the reference's (niter, nfeval, rc); "
+          f"third-trial (lb - thr) / marg from {bo.min():.3g} to {bo.max():.3g}, (f - thr) / marg from {to.min():.3g} to {to.max():.3g}")
+    if maxupd == 1 or not prec:
+        assert same == total        # the first line search is decided by the construction, in both precisions; fp64 all the way
+    else:
+        assert same >= 0.9 * total  # fp32, later iterations: Armijo decisions at rounding level (as everywhere in this file)

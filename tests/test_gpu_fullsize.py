@@ -144,6 +144,30 @@ def _row_lengths(trip, which):
     return np.bincount(major, minlength=trip.shape[0] if which else trip.shape[1])
 
 
+def _stratified_rows(rng, lengths, plan, total):
+    """Rows to check, taken from EVERY launch of the half-sweep just run (round 4; a uniform sample of a power-law half never met the
+    rows that matter: config C5's 60 rows above 8192 nonzeros, config C3's 300 multi-CU rows).  `plan` lists the launches in the
+    order of the device's row sort (longest rows first); position p of that order is approximated by sorting the triplet counts --
+    duplicates move a few rows across a boundary, no launch is missed.  Every launch contributes min(its rows, total / launches,
+    at least 24) rows -- all of its rows when it has fewer -- and a uniform sample fills up to `total`.
+    Returns (sorted rows, {launch name: rows taken})."""
+    order = np.argsort(-np.asarray(lengths, np.int64), kind="stable")
+    per = max(24, total // max(len(plan), 1))
+    picks, taken, pos = [], {}, 0
+    for name, n in plan:
+        seg = order[pos:pos + n]
+        pos += n
+        m = min(len(seg), per)
+        if m:
+            picks.append(rng.choice(seg, m, replace=False))
+            taken[name] = taken.get(name, 0) + m
+    got = np.unique(np.concatenate(picks)) if picks else np.zeros(0, np.int64)
+    if len(got) < total:
+        rest = np.setdiff1d(rng.choice(len(lengths), min(len(lengths), 2 * total), replace=False), got)[:total - len(got)]
+        got = np.union1d(got, rest)
+    return np.sort(got), taken
+
+
 def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True, warm_sweeps=0):
     """Runs one B half and one A half on the full matrix and checks SAMPLE rows of each against the oracle.  Returns the
     observed maxima so that the caller's tolerances are measured numbers.  warm_sweeps > 0: that many full sweeps run first, so
@@ -177,7 +201,8 @@ def _fullsize_halves(trip, k, method, use_float, maxupd, reuse_prev=True, warm_s
             A1, B1 = s.get_factors()
             M1, F = (A1, prevB) if which else (B1, prevA)
             Mprev = prevA if which else prevB
-            rows = np.sort(rng.choice(M1.shape[0], SAMPLE, replace=False))
+            rows, strata = _stratified_rows(rng, _row_lengths(trip, which), s.plan(which), SAMPLE)
+            stats[f"strata{which}"] = strata
             sd, si, sptr = _sub_from_triplets(trip, which, rows, use_float)
             G = M1[rows]
             # Two column-sum vectors.  "ref": the reference's serial real_t accumulation in row order (sum_by_cols, ref:

@@ -348,15 +348,19 @@ def test_transform_matches_fit_rows(prec):
 
 
 # ------------------------------------------------------------------ long-row path: a workgroup of 8 waves per row
-@pytest.mark.parametrize("method,k", [("pg", 50), ("cg", 50), ("tncg", 50), ("cg", 100), ("pg", 7)])
+@pytest.mark.parametrize("method,k", [("pg", 50), ("cg", 50), ("tncg", 50), ("cg", 100), ("pg", 7), ("tncg", 100)])
 def test_long_row_workgroup_path(prec, method, k, monkeypatch):
     """POISMF_HIP_LONGROW_NNZ lowers the threshold above which one row is handled by 8 cooperating wavefronts
     (row_eval.hpp, NW > 1), so the path that the power-law tail of config C5 takes is exercised on a small matrix:
-    rows with 65 .. ~10^4 nonzeros go through it, shorter ones through the wave-per-row kernel."""
+    rows with 65 .. ~10^4 nonzeros go through it, shorter ones through the wave-per-row kernel.  (tncg, k = 100) is config C5's own
+    instance: half_sweep_kernel<double,tncg,NW=8,streamed> with the compile-time slot count of PMF_LONG_SPECIAL and the
+    hipStreamWaitValue32 hold-back of the other bins (the long rows run on the second stream)."""
     monkeypatch.setenv("POISMF_HIP_LONGROW_NNZ", "64")
     csr, csc, A0, B0 = H.small_problem(3000, 2000, 120000, k, prec, seed=5, powerlaw=True, empty_rows=(3, 2999))
     assert np.diff(csc[2].astype(np.int64)).max() > 2000
-    kw = dict(maxupd=60) if method == "tncg" else {}
+    # (tncg: enough evaluations for the fp64 rows to converge at k = 100 too -- a truncated run ends wherever its last accepted step
+    # left it, see test_row_lengths_on_both_sides_of_every_hand_over)
+    kw = dict(maxupd=60 if k == 50 else (60 if prec else 400)) if method == "tncg" else {}
     A, B, args = gpu_run(csr, csc, A0, B0, method, 1, k, **kw)
     Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
     if method == "pg" and prec and np.isfinite(Ar).all():
