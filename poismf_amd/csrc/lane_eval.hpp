@@ -47,6 +47,13 @@ namespace pmf {
 #ifndef PMF_LANE_PREFETCH
 #define PMF_LANE_PREFETCH 1
 #endif
+// slots per group of the dots' software pipeline (eval(): the point and the LDS sets' slots of the NEXT group are requested before
+// the current group's multiply-adds: 2 x GQ x (1 + LDS sets) 16-byte values in flight).  Five where registers allow it; the instances
+// with two AGPR sets are at 512 registers, and the buffers of five-slot groups were what sent them to scratch (round 3: 68 / 96 / 96 /
+// 420 bytes per lane for one / two / four waves per row / with the partial set) -- three slots, two with the partial set: 0 / 0 / 0 / 56.
+#ifndef PMF_LANE_GQ
+#define PMF_LANE_GQ(la, lp) ((la) >= 2 ? ((lp) > 0 ? 2 : 3) : 5)
+#endif
 
 // a + b where lanes with bit 5 (W = 32) / bit 4 (W = 16) clear collect `a` and the others collect `b`: every lane ends
 // with its own copy of the operand it collects plus the partner lane's (lane ^ W) copy of the same operand.
@@ -164,6 +171,57 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // bytes between the 16-element rows of the transpose scratch: 18 doubles / 20 floats -- 36 c / 20 c banks for column c are
     // sixteen different multiples of 4 (mod 64), so the 16 lanes of a ds_read_b128 service group never share a bank
     static constexpr int RED_STRIDE = sizeof(T) == 8 ? 18 * 8 : 20 * 4;
+#ifndef PMF_LANE_XPOSE
+#define PMF_LANE_XPOSE 2   // 0: swap folds + 16-lane transposes through LDS (round 3); 1: the whole reduction through an LDS image; 2: DPP butterfly + 2 swap levels
+#endif
+    // XPOSE (round 4; floats, every set in architectural registers): the gradient's 64-lane sums go through LDS WHOLE -- every lane
+    // writes its KP lane-partials as KS 16-byte slots, every lane then adds up 16 lanes' worth of one slot-column and a quad of
+    // lanes is combined by two DPP adds -- instead of through two levels of v_permlane32/16_swap folds and a 16-lane transpose.
+    // Why: the probe of round 4 (scripts/probes/probe_lane.py) put the swap-fold reduction at 2 936 of a pass's 3 614 cycles on the
+    // headline's item rows: a v_permlane*_swap whose operands come straight out of a multiply-add chain and whose result feeds an add
+    // costs ~60 cycles of LATENCY (the 10 cycles of scripts/probes/valu_probe.hip are its issue rate back to back), and with 208 of
+    // 254 registers holding the tile the 39 swaps of a pass run strictly one after the other.  The LDS version has one round trip.
+    // k-vectors then live lane <-> dimension LINEARLY (dimension d in lane d): lane 4 q + e ends up with the sum of dimension 4 q + e.
+    // Image: slot-column q (dimensions 4 q .. 4 q + 3) of lane l at slot XP_QS q + l + l / 16 -- one pad slot per 16 lanes and a
+    // column stride = 4 (mod 16) make both the writes (a lane's own slot) and the reads (lane 4 q + p reads lanes 16 p .. 16 p + 15 of
+    // column q: the 16 lanes of a ds_read_b128 service group hit 16 different bank quads) conflict-free.
+    static constexpr bool XPOSE = PMF_LANE_XPOSE && sizeof(T) == 4 && LL_ == 0 && LP_ == 0 && (KP + WAVE - 1) / WAVE == 1;
+    static constexpr int XP_QS = 68;
+#ifndef PMF_LANE_COAL
+#define PMF_LANE_COAL 1
+#endif
+#ifndef PMF_LANE_PF_LDS
+#define PMF_LANE_PF_LDS 0   // measured and NOT adopted (scripts/probes/time_bhalf.py, C4 matrix, the 78.7 k item rows of 513 .. 1024 nonzeros):
+                            // 4.41 ms with it, 4.26 without at ten passes (3.20 against 3.25 at six) -- see PF_LDS below
+#endif
+#ifdef PMF_ABLATE_DOTS
+#define PMF_ABLATE_DOTS_ON 1
+#else
+#define PMF_ABLATE_DOTS_ON 0
+#endif
+#ifndef PMF_LANE_BANKED
+#define PMF_LANE_BANKED 0   // 1: the butterfly's two upper levels as bank-masked DPP adds on full batches of sixteen (43 fewer instructions per pass, 16 more
+                            // live registers: the headline instance then spills 16-24 bytes per lane; measured on the C4 matrix: 4.25 ms either way)
+#endif
+    // COAL (round 4; with XPOSE): the register sets are fetched by COALESCED loads -- instruction i of a set reads the 64 consecutive
+    // 16-byte slots 64 i .. 64 i + 63 of the row-major image [nonzero][W slots], i.e. W adjacent lanes share a factor row, as the
+    // LDS-DMA chunks do -- straight into the tile's own registers (all sets of a row in flight at once), and each set is then turned
+    // into "one nonzero per lane" by one trip through the XPOSE image in LDS (W ds_write_b128, W ds_read_b128).  The per-lane loads
+    // this replaces named 64 different factor rows per instruction; the 13 instructions that touch a row's two lines were spread over
+    // the whole gather of eight waves, far beyond what the 32 KB L1 keeps, so every 16-byte request was served by L2 again: the probe
+    // of round 4 put the gather of a 1000-nonzero fp32 row at 26 k of its 62 k cycles.
+    static constexpr bool COAL = PMF_LANE_COAL && XPOSE && LA_ == 0 && PMF_LANE_DIRECT;
+    static_assert(!COAL || (STAGE_BYTES <= KS * XP_QS * 16 && KS == W), "a whole set's image fits the reduction's image");
+    // PF_LDS (round 4; with COAL and the butterfly reduction, which leaves the LDS image idle during a solve): while a row is being
+    // solved, the FIRST SET of the next row's tile is fetched into that image by LDS-DMA (prefetch_tile(), called by pg_row after its
+    // first pass: the next row's indices have landed by then and no register is needed); the row switch then reads that set out of LDS
+    // and fetches only the other sets from memory.  The ablation runs of round 4 (scripts/probes/time_bhalf.py) put this launch at
+    // gather floor + the part of ten passes that does not hide under the OTHER workgroup's gather: a quarter of every gather moved
+    // under the row's own passes.  The registers hold one tile and no more; LDS holds 13 KB per wave: one set of four.
+    // Result: slower.  The thirteen DMA instructions and their address arithmetic are issued by the wave that is computing (a
+    // hundred-odd instructions per row on a SIMD that is the bottleneck while both workgroups of a CU compute), and what they save is a
+    // quarter of a gather that the other workgroup's passes were already covering most of the time.
+    static constexpr bool PF_LDS = PMF_LANE_PF_LDS && COAL && PMF_LANE_XPOSE == 2;
 #ifndef PMF_LANE_FIVE
 #define PMF_LANE_FIVE 0   // doubles, one VGPR set + one LDS set, one wave per row: the scratch in two halves brings a wave's LDS from 36.3 to 31.1 KB,
                           // i.e. FIVE rows per CU instead of four, one SIMD taking two waves.  Measured, C3 A half: 19.8 -> 23.9 ms (maxupd 1:
@@ -173,7 +231,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr bool FIVE = PMF_LANE_FIVE && sizeof(T) == 8 && LV_ == 1 && LA_ == 0 && LL_ == 1 && NW_ == 1 && !PF_ && LP_ == 0;
     static constexpr int RED_PH = (LP_ > 0 || FIVE) ? 2 : 1;        // the columns pass through the scratch in this many groups
     static constexpr int RED_COLS = RED_PH == 1 ? 16 : (CW + 1) / 2;
-    static constexpr int RED_BYTES = 4 * RED_COLS * RED_STRIDE; // four 16-lane rows x the columns of a group
+    static constexpr int RED_BYTES = XPOSE ? KS * XP_QS * 16 : 4 * RED_COLS * RED_STRIDE; // four 16-lane rows x the columns of a group
     // one chunk of the partial set: LP_ rows of W slots, rounded up to whole DMA instructions (64 lanes x 16 bytes) so that no
     // lane has to be masked off -- the lanes past the image fetch some row's slots into the padding
     static constexpr int PART_BYTES = LP_ > 0 ? (LP_ * W * 16 + 1023) / 1024 * 1024 : 0;
@@ -229,6 +287,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         __device__ __forceinline__ int operator[](int i) const { return d0 + DB * i; }
     } elem;
     bool act[NC];
+    bool holds_dim;      // this lane holds a dimension of the padded k-vector (elem.d0 < DB)
+    bool meta_fresh;     // PF_LDS: idx_n holds the indices of a row whose tile has not been requested yet (fetch_meta -> prefetch_tile / gather)
+    bool pf_have;        // PF_LDS: the image holds (or is receiving) set 0 of the row idx_n names
     unsigned nnz;        // nonzeros of the row held by THIS wave
     unsigned n_eval;
     unsigned char* stage;   // this wave's NBUF staging buffers
@@ -259,8 +320,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         nbar = 0;
         smem += (size_t)half * HALF_BYTES;
         const int col = lane & 15, rr = lane >> 4;
-        elem.d0 = col + CW * rr;
-        const bool lane_on = col < CW && elem.d0 < DB;
+        elem.d0 = XPOSE ? lane : col + CW * rr;
+        const bool lane_on = XPOSE ? lane < DB : (col < CW && elem.d0 < DB);
+        holds_dim = lane_on;
         F = F_;
         k = geo.k; ldF = geo.ldF; zero_row = geo.zero_row;
         unsigned char* p = smem + (size_t)wid * WAVE_BYTES;
@@ -274,6 +336,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #pragma unroll
         for (int i = 0; i < NC; i++) act[i] = lane_on && elem[i] < k;
         pq_cap = 0x7fffffff;
+        meta_fresh = false; pf_have = false;
         pbuf = (T*)(size_t)16; qbuf = (T*)(size_t)32;   // tags, never dereferenced
         n_eval = 0;
         nnz = 0;
@@ -440,6 +503,34 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             const unsigned j = (unsigned)(WAVE * s + lane);
             idx_n[s] = j < mine ? ind[c0 + j] : zero_row;   // lanes past the end of the row fetch the all-zero row behind F
         }
+        if constexpr (PF_LDS) meta_fresh = true;
+    }
+    // PF_LDS: set 0 of the row whose indices fetch_meta fetched last -> the LDS image, as W LDS-DMA instructions (the row-major image
+    // [nonzero][W slots] the coalesced gather builds through registers).  Called from inside the solve of the CURRENT row.
+    __device__ __forceinline__ void prefetch_tile()
+    {
+        if constexpr (PF_LDS) {
+            if (!meta_fresh) return;
+            meta_fresh = false;
+            pf_have = true;
+            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+            unsigned lane_here = (unsigned)lane;
+            asm volatile("" : "+v"(lane_here));
+            unsigned j4 = (lane_here / (unsigned)W) * 4u;
+            unsigned q16 = (lane_here % (unsigned)W) * 16u;
+            static_for<0, W>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                const unsigned c = (unsigned)__builtin_amdgcn_ds_bpermute((int)j4, (int)idx_n[0]);
+                const unsigned off = __umul24(c, rowbytes) + q16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)F + (size_t)off),
+                                                 (__attribute__((address_space(3))) void*)(red + i * 1024), 16, 0, 0);
+                j4 += (unsigned)(WAVE / W) * 4u;
+                q16 += (unsigned)(WAVE % W) * 16u;
+                const bool wrap = q16 >= (unsigned)(W * 16);
+                q16 = wrap ? q16 - (unsigned)(W * 16) : q16;
+                j4 = wrap ? j4 + 4u : j4;
+            });
+        }
     }
     __device__ __forceinline__ void begin_row(const unsigned* ind, const T* val, unsigned nnz_row)
     {
@@ -528,7 +619,71 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             }
         };
         if constexpr (TEMP_A && LL > 0) request_lds_sets();   // nothing is staged: their buffers are free now
-        if constexpr (DIRECT_V) {
+        if constexpr (COAL) {
+            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+            // (the W (row, slot) pairs of a lane are the same for every row of the launch; derived from an opaque copy of the lane
+            // number they are recomputed here -- five VALU instructions each -- instead of being kept in 26 registers across the
+            // solver, i.e. in scratch)
+            unsigned lane_here = (unsigned)lane;
+            asm volatile("" : "+v"(lane_here));
+            // (PF_LDS: set 0 is in the image already, or on its way there)
+            const bool have0 = PF_LDS && pf_have;
+            if constexpr (PF_LDS) { pf_have = false; meta_fresh = false; }
+            auto request_set = [&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                unsigned j4 = (lane_here / (unsigned)W) * 4u;            // byte address of the row's index for ds_bpermute
+                unsigned q16 = (lane_here % (unsigned)W) * 16u;
+                static_for<0, W>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const unsigned c = (unsigned)__builtin_amdgcn_ds_bpermute((int)j4, (int)idx[s2]);
+                    const unsigned off = __umul24(c, rowbytes) + q16;
+                    const typename Slot<T>::U v = *(const typename Slot<T>::U*)((const char*)F + (size_t)off);
+#pragma unroll
+                    for (int e = 0; e < SN; e++) t[s2][i * SN + e] = v.v[e];
+                    j4 += (unsigned)(WAVE / W) * 4u;
+                    q16 += (unsigned)(WAVE % W) * 16u;
+                    const bool wrap = q16 >= (unsigned)(W * 16);
+                    q16 = wrap ? q16 - (unsigned)(W * 16) : q16;
+                    j4 = wrap ? j4 + 4u : j4;
+                });
+            };
+            // image order -> one nonzero per lane through the image
+            auto own_rows_of_image = [&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                const SA* rd = (const SA*)red + lane * W;
+                static_for<0, W>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const SA v = rd[q];
+#pragma unroll
+                    for (int e = 0; e < SN; e++) t[s2][q * SN + e] = v.v[e];
+                });
+                wave_lds_fence();
+            };
+            auto through_image = [&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                SA* wr = (SA*)red + lane;
+                static_for<0, W>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    SA v;
+#pragma unroll
+                    for (int e = 0; e < SN; e++) v.v[e] = t[s2][i * SN + e];
+                    wr[i * WAVE] = v;
+                });
+                wave_lds_fence();
+                own_rows_of_image(sc);
+            };
+            if (have0) {
+                // the other sets' loads go out first; then the prefetched set leaves the image, which is the staging buffer after that
+                static_for<1, LV>(request_set);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LV - 1) * W < 63 ? (LV - 1) * W : 63) : "memory");   // (the DMA is older than those loads)
+                wave_lds_fence();
+                own_rows_of_image(std::integral_constant<int, 0>{});
+                static_for<1, LV>(through_image);
+            } else {
+                static_for<0, LV>(request_set);
+                static_for<0, LV>(through_image);
+            }
+        } else if constexpr (DIRECT_V) {
             const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
             static_for<0, LV>([&](auto sc) {
                 constexpr int s2 = decltype(sc)::value;
@@ -635,7 +790,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         wave_lds_fence();
 #pragma unroll
         for (int i = 0; i < NC; i++)
-            if ((lane & 15) < CW && elem.d0 < DB) a[elem[i]] = act[i] ? x[i] : (T)0;   // (dimensions k .. KP - 1 of the padded row: zeros)
+            if (holds_dim) a[elem[i]] = act[i] ? x[i] : (T)0;   // (dimensions k .. KP - 1 of the padded row: zeros)
         wave_lds_fence();
     }
 
@@ -735,6 +890,121 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     }
     template <int B> __device__ __forceinline__ T reduce_block(const T (&coef)[LT])
     {
+        if constexpr (XPOSE && PMF_LANE_XPOSE == 2) {
+            // (mode 2) No LDS and three swaps: inside every 16-lane row the KP lane-partials are summed by reg_eval.hpp's TRANSPOSING
+            // BUTTERFLY, sixteen at a time -- four levels of "keep the register your lane class collects, add the partner lane's copy of
+            // it" (two selects and one DPP add per fold, 15 folds per batch) leave the row's sum of partial 16 b + g in lane g -- and
+            // the four rows' sums of the (up to) four batches meet in two swap folds: row r ends up with batch r, i.e. lane l with the
+            // total of dimension l.  ~160 VALU instructions for 52 dimensions, dependent chains of six operations.
+            static_assert(B == 0 && KP <= WAVE, "one element per lane");
+#ifdef PMF_ABLATE_REDUCE   // development: what a pass costs WITHOUT the reduction (wrong results, same control flow)
+            {
+                T u = coef[0] * t[0][0];
+                static_for<1, LV>([&](auto sc) { u = fma_t(coef[decltype(sc)::value], t[decltype(sc)::value][decltype(sc)::value], u); });
+                return u;
+            }
+#endif
+            const bool c8 = (lane & 8) != 0, c4 = (lane & 4) != 0, c2 = (lane & 2) != 0, c1 = (lane & 1) != 0;
+            constexpr int NBATCH = (KP + 15) / 16;
+            T rowsum[4] = { (T)0, (T)0, (T)0, (T)0 };
+            static_for<0, NBATCH>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                constexpr int N = KP - 16 * b < 16 ? KP - 16 * b : 16;        // partials of this batch
+                T q[8], r[4], s2[2];
+                constexpr int N8 = N < 8 ? N : 8;
+                if constexpr (N == 16 && PMF_LANE_BANKED) {
+                    // a full batch: all sixteen lane-partials (sixteen independent multiply-add chains, SET-major), then the two upper
+                    // levels as bank-masked DPP adds -- two instructions per fold instead of two selects and an add (reg_eval.hpp)
+                    T u[16];
+                    static_for<0, LV>([&](auto sc) {
+                        constexpr int s_ = decltype(sc)::value;
+                        static_for<0, 16>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            if constexpr (s_ == 0) u[j] = coef[0] * t[0][16 * b + j];
+                            else u[j] = fma_t(coef[s_], t[s_][16 * b + j], u[j]);
+                        });
+                    });
+                    fold16_banked(u, q);
+                    fold8_banked(q, r);
+                } else {
+                    // the lane-partials of eight dimensions at a time, SET-major: eight independent multiply-add chains side by side
+                    // (column by column the chains were two wide: a dependent v_fmac every other instruction)
+                    static_for<0, 2>([&](auto hc) {
+                        constexpr int h = decltype(hc)::value;
+                        T u[8];
+                        // chain j: dimension 16 b + 4 h + j / 2 + 8 (j % 2)   (the two inputs of fold 4 h + j / 2)
+                        static_for<0, LV>([&](auto sc) {
+                            constexpr int s_ = decltype(sc)::value;
+                            static_for<0, 8>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                constexpr int d = 4 * h + j / 2 + 8 * (j % 2);
+                                if constexpr (d < N) {
+                                    constexpr int C = 16 * b + d;
+                                    if constexpr (s_ == 0) u[j] = coef[0] * t[0][C];
+                                    else u[j] = fma_t(coef[s_], t[s_][C], u[j]);
+                                }
+                            });
+                        });
+                        static_for<0, 4>([&](auto ic) {                             // lane ^ 8 (row_ror:8)
+                            constexpr int i = 4 * h + decltype(ic)::value;
+                            constexpr int j = 2 * decltype(ic)::value;
+                            if constexpr (i + 8 < N) q[i] = fold_pair<0x128>(c8, u[j], u[j + 1]);
+                            else if constexpr (i < N) q[i] = fold_one<0x128>(u[j]);
+                            else q[i] = (T)0;
+                        });
+                    });
+                    fold_level<0x141, 4, N8>(c4, q, r);                             // lane ^ 7 (row_half_mirror)
+                }
+                constexpr int N4 = N8 < 4 ? N8 : 4;
+                fold_level<0x4E, 2, N4>(c2, r, s2);                             // lane ^ 2
+                constexpr int N2 = N4 < 2 ? N4 : 2;
+                if constexpr (N2 == 2) rowsum[b] = fold_pair<0xB1>(c1, s2[0], s2[1]);   // lane ^ 1
+                else rowsum[b] = fold_one<0xB1>(s2[0]);
+#ifdef PMF_PROBE
+                asm volatile("" : "+v"(rowsum[b]));
+                PMF_STAMP(*this, 5 + b);
+#endif
+            });
+            // rows 0 | 2 collect batch 0 | 2, rows 1 | 3 batch 1 | 3
+            const T x = swap_fold<32>(rowsum[0], rowsum[2]), y = swap_fold<32>(rowsum[1], rowsum[3]);
+            return swap_fold<16>(x, y);
+        }
+        if constexpr (XPOSE) {
+            static_assert(B == 0 && SN == 4, "floats, one element per lane");
+            SA* img = (SA*)red + (lane + (lane >> 4));
+            static_for<0, KS>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                SA v;
+                static_for<0, SN>([&](auto ec) {
+                    constexpr int C = q * SN + decltype(ec)::value;
+                    T u = coef[0] * t[0][C];
+                    static_for<1, LV>([&](auto sc) { u = fma_t(coef[decltype(sc)::value], t[decltype(sc)::value][C], u); });
+                    v.v[C % SN] = u;
+                });
+                img[q * XP_QS] = v;
+            });
+            wave_lds_fence();
+            // lane 4 q + p: lanes 16 p .. 16 p + 15 of slot-column q, in lane order; then the four quarters (p0 + p1) + (p2 + p3)
+            // (lanes past the last slot-column hold no dimension: they read column q - 4 -- valid memory, and 4 x 68 slots further down
+            // is the same bank quad as their own column would be, so their service group stays conflict-free)
+            static_assert(KS >= 12 && KS <= 16, "slot-columns of the lanes past 4 KS");
+            const int qr = (lane >> 2) < KS ? (lane >> 2) : (lane >> 2) - 4, pr = lane & 3;
+            const SA* rd = (const SA*)red + (qr * XP_QS + 17 * pr);
+            SA a = rd[0];
+#pragma unroll
+            for (int i = 1; i < 16; i++) {
+                const SA b = rd[i];
+#pragma unroll
+                for (int e = 0; e < SN; e++) a.v[e] += b.v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < SN; e++) a.v[e] = a.v[e] + dpp_mov<0xB1>(a.v[e]);   // quad_perm [1, 0, 3, 2]
+#pragma unroll
+            for (int e = 0; e < SN; e++) a.v[e] = a.v[e] + dpp_mov<0x4E>(a.v[e]);   // quad_perm [2, 3, 0, 1]
+            const T r01 = (pr & 1) ? a.v[1] : a.v[0], r23 = (pr & 1) ? a.v[3] : a.v[2];
+            wave_lds_fence();                              // (the image is rewritten by the next pass)
+            return (pr & 2) ? r23 : r01;                   // lane 4 q + p: dimension 4 q + p
+        }
         const int R = lane >> 4, p = lane & 15;
         unsigned char* wr = red + R * (RED_COLS * RED_STRIDE) + p * (int)sizeof(T);
         T tl[2][4][LLX];
@@ -817,8 +1087,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         if constexpr (FROM_CACHE) {
 #pragma unroll
             for (int s = 0; s < LT; s++) pred[s] = pv[s];
+        } else if constexpr (SPOINT && PMF_ABLATE_DOTS_ON) {   // development: what a pass costs WITHOUT the dots
+            static_for<0, LT>([&](auto sc) { constexpr int s2 = decltype(sc)::value; pred[s2] = fma_t(t[s2][s2], xcur, (T)1); });
         } else if constexpr (SPOINT) {
-            // dimension c of the point sits in lane (c % CW) + 16 (c / CW): one v_readlane, then a scalar operand of LT multiply-adds
+            // dimension c of the point sits in lane (c % CW) + 16 (c / CW) (XPOSE: in lane c): one v_readlane, then a scalar operand of LT multiply-adds
             // (read in groups of GS ahead of their use: a v_readlane's SGPR needs two wait states before a VALU may read it)
             constexpr int GS = 4;
             static_for<0, (KP + GS - 1) / GS>([&](auto gc) {
@@ -827,7 +1099,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 static_for<0, GS>([&](auto ic) {
                     constexpr int c = c0 + decltype(ic)::value;
                     if constexpr (c < KP) {
-                        ac[c - c0] = read_lane(xcur, (c % CW) + 16 * (c / CW));
+                        ac[c - c0] = read_lane(xcur, XPOSE ? c : (c % CW) + 16 * (c / CW));
                         asm volatile("" : "+s"(ac[c - c0]));   // here, not sunk next to its use
                     }
                 });
@@ -845,7 +1117,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         } else {
             // slots in groups of GQ: the point (a broadcast read) and the LDS sets' slots of the NEXT group are requested
             // before the current group's multiply-adds
-            constexpr int GQ = 5, NG = (KS + GQ - 1) / GQ;
+            constexpr int GQ = PMF_LANE_GQ(LA_, LP_), NG = (KS + GQ - 1) / GQ;
             SA av[2][GQ], tl[2][LLX][GQ];
             auto load_group = [&](auto gc, SA (&a_)[GQ], SA (&t_)[LLX][GQ]) {
                 constexpr int g = decltype(gc)::value;

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/poismf_hip.h"
 #include "row_eval.hpp"
@@ -214,6 +215,9 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
 #define PMF_LANE_PG32 0   // measured, C4 matrix, PG(10) fp32, B half: 9.5 ms against 8.0 ms for reg_eval.hpp's eight-wave kernels: a pass of
                           // either is ~5 k cycles of barrier / LDS round trips in lockstep, which the cheaper instruction stream does not shorten
 #endif
+#ifndef PMF_LANE_PG_LONG
+#define PMF_LANE_PG_LONG 0
+#endif
 #ifndef PMF_LANE_PG32X4
 #define PMF_LANE_PG32X4 1   // rows of 513 .. 1024 nonzeros on FOUR waves of four sets each (three in registers, one in LDS), two such rows per CU
 #endif
@@ -226,7 +230,10 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
             // (1025 .. 1152 nonzeros: 4.5 sets per wave do not fit; six waves x three sets, one row per CU, measured 2.50 ms against 1.85 ms
             // for reg_eval.hpp's eight-wave kernel on the 21 k such rows of the C4 matrix -- they stay there)
             if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };
-            if (PMF_LANE_PG32 && cls > 1024 && cls <= 1536) return { 3, 0, 0, 8, 1 };
+            // rows of 1025 .. 1536 nonzeros: eight waves of three sets, one row per CU (tuning knob POISMF_HIP_PG_LONG_LANE=0 / 1:
+            // the register engine's eight-wave kernels / this instance)
+            static const int long_lane = getenv("POISMF_HIP_PG_LONG_LANE") ? atoi(getenv("POISMF_HIP_PG_LONG_LANE")) : PMF_LANE_PG_LONG;
+            if ((PMF_LANE_PG32 || long_lane) && cls > 1024 && cls <= 1536) return { 3, 0, 0, 8, 1 };
             return { 0, 0, 0, 0, 0 };
         }
         if (cls <= 64) return { 1, 0, 0, 1, 1 };

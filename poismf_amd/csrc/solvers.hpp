@@ -12,6 +12,9 @@
 //              :1664-1813 (linearSearch), :1822-2154 (getptcInit/getptcIter), with tncg_iteration's
 //              constants, src/poismf.c:383-391
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "row_eval.hpp"
 
 namespace pmf {
@@ -19,6 +22,10 @@ namespace pmf {
 #define PMF_EW _Pragma("unroll") for (int i = 0; i < NC; i++)
 
 template <class T> __device__ __forceinline__ bool not_finite(T v) { return isnan(v) || isinf(v); }
+
+// engines that can fetch part of the NEXT row's tile while the current row is being solved say so by having prefetch_tile()
+template <class E, class = void> struct has_prefetch_tile : std::false_type {};
+template <class E> struct has_prefetch_tile<E, std::void_t<decltype(std::declval<E&>().prefetch_tile())>> : std::true_type {};
 
 // What a row's solver decided, for tests that pin the decisions and not only the result (the reference hands the same numbers
 // back from minimize_nonneg_cg -- niter, nfeval, ref: src/nonnegcg.c:177-189 -- and from tnc -- nfeval, niter, rc, ref:
@@ -43,6 +50,8 @@ __device__ __forceinline__ void pg_row(EV& ev, const RowParams<T>& P, T (&x)[NC]
             x[i] = x[i] * P.cnst_div;                              // a *= 1 / (1 + 2 l2 step)
             x[i] = (x[i] > (T)0) ? x[i] : (T)0;                    // a = max(a, 0)
         }
+        // (engines that can: the next row's tile starts travelling now, under the remaining passes of this one)
+        if constexpr (has_prefetch_tile<EV>::value) { if (u == 0) ev.prefetch_tile(); }
         PMF_STAMP(ev, 9);
     }
 }

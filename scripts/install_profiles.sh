@@ -1,22 +1,25 @@
 #!/bin/bash
-# usage: scripts/install_profiles.sh <tag> [round dir, default r03]: copy what scripts/profile_round.sh left in
-# gpurun_out/<tag>/ into profiles/<round>/ (tracked) and refresh profiles/hbm_traffic.json
+# usage: scripts/install_profiles.sh <tag> [round dir, default r04]: copy what scripts/profile_round.sh left in
+# gpurun_out/<tag>/ into profiles/<round>/ (tracked) and refresh profiles/hbm_traffic.json.  Only the files this script writes are
+# replaced: whatever else lives in the round's directory (probe outputs, run_config records, kernel_resource_usage.txt) stays.
 set -e
 cd "$(dirname "$0")/.."
-SRC=gpurun_out/$1; DST=profiles/${2:-r03}
-KEEP=$(mktemp -d); [ -d $DST/run_config ] && cp -r $DST/run_config $KEEP/   # (scripts/run_config.py's records live there too)
-rm -rf $DST; mkdir -p $DST/pmc
-[ -d $KEEP/run_config ] && cp -r $KEEP/run_config $DST/; rm -rf $KEEP
+SRC=gpurun_out/$1; DST=profiles/${2:-r04}
+mkdir -p $DST/pmc
 cp $SRC/bench_line.json $DST/bench_line.json
-for n in pg10 pg1 cg64 cg32 tncg32; do
+for n in pg10 pg1 cg64 cg32 tncg32 c5; do
+  [ -f $SRC/kt_$n/kt_kernel_stats.csv ] || continue
   cp $SRC/kt_$n/kt_kernel_stats.csv $DST/kt_${n}_kernel_stats.csv
-  cp $SRC/kt_${n}_bench_line.json $DST/
-  for c in f w t sq; do cp $(find $SRC/pmc_${c}_$n -name summary.txt | head -1) $DST/pmc/pmc_${c}_${n}.summary.txt; done
+  [ -f $SRC/kt_${n}_bench_line.json ] && cp $SRC/kt_${n}_bench_line.json $DST/
+  [ -f $SRC/kt_${n}_run_config.json ] && cp $SRC/kt_${n}_run_config.json $DST/
+  for c in f w t sq; do f=$(find $SRC/pmc_${c}_$n -name summary.txt 2>/dev/null | head -1); [ -n "$f" ] && cp $f $DST/pmc/pmc_${c}_${n}.summary.txt; done
 done
 cp $SRC/hbm_traffic.json profiles/hbm_traffic.json
 python3 - <<PY
-import csv, json
+import csv, json, os
 for tag, n in (("kt_pg10", 12), ("kt_pg1", 12), ("kt_cg64", 6), ("kt_cg32", 6), ("kt_tncg32", 6)):
+    if not os.path.exists(f"$DST/{tag}_kernel_stats.csv"):
+        continue
     rows = list(csv.DictReader(open(f"$DST/{tag}_kernel_stats.csv")))
     tot = sum(float(r["TotalDurationNs"]) for r in rows if "half_sweep" in r["Name"])
     d = json.loads(open(f"$DST/{tag}_bench_line.json").read())

@@ -18,12 +18,13 @@ out = np.zeros(16 * 60, np.uint32)
 s.lib.poismf_hip_debug_eval_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
 assert s.lib.poismf_hip_debug_eval_rows(s.h, 0, out.ctypes.data_as(C.c_void_p), len(out)) == 0
 t = out.reshape(60, 16).astype(np.int64)
-names = ["dots", "coef", "reduce", "combine", "update(to stamp 9)"]
+names = ["dots", "coef", "reduce", "combine", "update(to stamp 9)", "| reduce: batch0", "batch1", "batch2", "batch3", "swaps"]
 print("nnz | " + " | ".join(names) + " || row total (start to next row's start)")
 rows = []
 for i in range(2, 58):
     r = t[i]
     d = [int((r[j + 1] - r[j]) & 0xffffffff) for j in range(4)] + [int((r[9] - r[4]) & 0xffffffff)]
+    d += [int((r[5] - r[2]) & 0xffffffff), int((r[6] - r[5]) & 0xffffffff), int((r[7] - r[6]) & 0xffffffff), int((r[8] - r[7]) & 0xffffffff), int((r[3] - r[8]) & 0xffffffff)]
     rows.append(d + [int((t[i + 1][10] - r[10]) & 0xffffffff)])
     if i < 10:
         print(int(r[11]), rows[-1])

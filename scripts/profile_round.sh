@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, through gpurun):  scripts/profile_round.sh <tag>
+# usage (on the GPU box, through gpurun):  scripts/profile_round.sh <tag> [round name stamped into hbm_traffic.json, default r04]
 # Produces gpurun_out/<tag>/: the default bench line, rocprofv3 --kernel-trace --stats of the workloads behind it (PG fp32
 # with maxupd 10 and 1, CG fp64, CG fp32, TNCG fp32, all on the 1M x 100K / 1e8-nnz matrix) and PMC passes (FETCH_SIZE and WRITE_SIZE separately,
 # TCC hit / miss, SQ issue / wait counters) of the same commands.  scripts/install_profiles.sh copies the summaries to profiles/.
@@ -26,9 +26,16 @@ run pg1 --steps 5 --warmup 1 --maxupd 1
 run cg64 --steps 2 --warmup 1 --method cg --fp64
 run cg32 --steps 2 --warmup 1 --method cg
 run tncg32 --steps 2 --warmup 1 --method tncg
+# config C5 (its own matrix, k = 100, tncg fp64) through scripts/run_config.py: 2 warm-up + 3 timed sweeps, no oracle sample
+C5="python3 $R/scripts/run_config.py C5 --warmup 2 --sweeps 3 --sample 0"
+rocprofv3 --kernel-trace --stats -d $OUT/kt_c5 -o kt --output-format csv -- $C5 > $OUT/kt_c5.log 2>&1
+grep '^{"config"' $OUT/kt_c5.log | tail -1 > $OUT/kt_c5_run_config.json
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f_c5 -o pmc --output-format csv -- $C5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w_c5 -o pmc --output-format csv -- $C5 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES -d $OUT/pmc_sq_c5 -o pmc --output-format csv -- $C5 > /dev/null 2>&1
 for f in $(find $OUT -name "*counter_collection.csv"); do python3 $R/scripts/pmc_summary.py $f 0 > $(dirname $f)/summary.txt; done
 find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*agent_info.csv" -delete
-python3 $R/scripts/traffic_from_pmc.py $OUT > $OUT/hbm_traffic.json
+python3 $R/scripts/traffic_from_pmc.py $OUT ${2:-r04} > $OUT/hbm_traffic.json
 cat $OUT/hbm_traffic.json

@@ -11,9 +11,14 @@ import re
 import sys
 
 root = sys.argv[1]
+round_tag = sys.argv[2] if len(sys.argv) > 2 else "?"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from poismf_amd import build  # noqa: E402  (the hash of the kernel sources + flags these counters were recorded from)
 # name -> (key in profiles/hbm_traffic.json, sweeps per profiled run = 2 x (warmup + steps) of scripts/profile_round.sh)
 RUNS = {"pg10": ("C4_pg_maxupd10_f32", 12), "pg1": ("C4_pg_maxupd1_f32", 12), "cg64": ("C4_cg_maxupd5_f64", 6),
-        "cg32": ("C4_cg_maxupd5_f32", 6), "tncg32": ("C4_tncg_f32", 6)}
+        "cg32": ("C4_cg_maxupd5_f32", 6), "tncg32": ("C4_tncg_maxupd750_f32", 6),
+        # config C5 through scripts/run_config.py (--warmup 2 --sweeps 3): five sweeps, the first two from the random start
+        "c5": ("C5_tncg_maxupd1500_f64", 5)}
 
 
 def total(path, counter):
@@ -26,9 +31,12 @@ def total(path, counter):
     return tot
 
 
-out = {"_note": "fabric-side bytes per full sweep of the half_sweep_* launches on the 1M x 100K / 1e8-nnz matrix, "
-                "(2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes "
-                "(scripts/profile_round.sh); Infinity-Cache hits are included, so this is an upper bound on DRAM traffic"}
+out = {"_note": "fabric-side bytes per full sweep of the half_sweep_* launches on the 1M x 100K / 1e8-nnz matrix (C5_*: on config C5's "
+                "matrix, averaged over the five sweeps of the profiled run), (2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE and WRITE_SIZE "
+                "from separate rocprofv3 --pmc passes (scripts/profile_round.sh); Infinity-Cache hits are included, so this is an upper "
+                "bound on DRAM traffic.  source_hash = poismf_amd.build's hash of the kernel sources + flags the counters were recorded "
+                "from: bench.py quotes an entry as roofline.traffic only while the tree still has that hash",
+       "round": round_tag, "source_hash": build._source_hash()}
 for name, (key, sweeps) in RUNS.items():
     # the key bench.py looks up: <workload>_<method>_maxupd<N>_<f32|f64>, read off the bench line of the same run when it is there
     try:

@@ -332,6 +332,11 @@ def test_c5_tncg_fp64_fullsize(c5_trip, reuse_prev, warm_sweeps):
         # slot engine of round 2 and the lane engine of round 3 both show the same kind of rows, 3.7e-8 .. 1.1e-2 in the sample's
         # total).  The yardstick is the reference against itself on the SAME rows: the GPU must be as close to the compiled
         # reference's flavour as the other flavour is (x3), and agree with it on as many rows (-3 %).
+        # Round 4: the samples are stratified by launch (150 of the A half's 300 rows now come from the 3 318 rows above 64 nonzeros, and
+        # the B half's include all 60 rows above 8 192), i.e. they hold far more of the rows on which TNC's last accepted step is a
+        # matter of rounding.  ONE such row ending 1.5 % (measured, A half) .. 29 % (B half, a 78-nonzero row; the reference's flavours
+        # show 20 % on rows of the same kind) away moves a 300-row total by 5e-5 .. 1e-3, whichever implementation it happens to: the
+        # floor of the total's bound is 2e-4 (was 5e-5 on uniform samples), the row-wise criterion is unchanged.
         for w in (0, 1):
-            assert st[f"obj{w}"] <= max(5e-5, 3.0 * st[f"self{w}"]), (w, st[f"obj{w}"], st[f"self{w}"])
+            assert st[f"obj{w}"] <= max(2e-4, 3.0 * st[f"self{w}"]), (w, st[f"obj{w}"], st[f"self{w}"])
             assert st[f"rows_close{w}"] >= min(0.97, st[f"self_rows_close{w}"] - 0.03), (w, st[f"rows_close{w}"], st[f"self_rows_close{w}"])
