@@ -33,6 +33,7 @@ import os
 import sys
 import time
 
+_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None   # (before libgomp binds this thread, below)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")  # the CPU baseline threads over rows with OpenMP, as the reference does
 # the CPU baseline runs with its OpenMP threads bound (read by libgomp when it is loaded: before numpy / torch)
 os.environ.setdefault("OMP_PROC_BIND", "close")
@@ -47,6 +48,16 @@ import torch.distributed as dist  # noqa: E402
 
 from poismf_amd import api, build, harness, synth  # noqa: E402
 from poismf_amd import dist as pdist  # noqa: E402
+
+# With OMP_PROC_BIND set, libgomp pins the thread that loads it -- this one -- to its first place, and every thread created from it
+# later inherits that one-core mask: the eight host threads that fill run_poismf's pinned upload chunks then share a core (measured:
+# the drop-in call's first iteration 80 -> 97 ms).  The main thread gets its mask back; the OpenMP workers of the CPU legs are still
+# bound to their places when their team is created.
+if _AFFINITY is not None:
+    try:
+        os.sched_setaffinity(0, _AFFINITY)
+    except OSError:
+        pass
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 WORKLOADS = {
@@ -269,8 +280,28 @@ def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
                             False, True, True, 1)
         t[numiter].append((time.perf_counter() - t0) * 1e3)
     t1, t6 = min(t[1][1:]), min(t[6])
+    # where a call's time goes: the same steps through the session entry points, each timed (min of 3): what run_poismf does inside
+    split = {"session_create_upload_X_and_sort": [], "factors_up": [], "one_iteration": [], "factors_down": [], "destroy": []}
+    for _ in range(3):
+        t0 = time.perf_counter()
+        sess = api.Session(csr, csc, dimA, dimB, K, use_float)
+        ta = time.perf_counter()
+        sess.set_factors(A0, B0)
+        tb = time.perf_counter()
+        prm = sess.make_params(method=method, l2_reg=l2, maxupd=maxupd, limit_step=True, early_stop=False, reuse_prev=True)
+        with np.errstate(all="ignore"):
+            sess.sweep(prm, 1e-7)
+        sess.kernel_time(0)   # (synchronises the session stream)
+        tc = time.perf_counter()
+        sess.get_factors()
+        td = time.perf_counter()
+        sess.close()
+        te = time.perf_counter()
+        for name, dt in zip(split, (ta - t0, tb - ta, tc - tb, td - tc, te - td)):
+            split[name].append(dt * 1e3)
     return {"abi_ms_first_iter": t1, "abi_ms_per_extra_iter": (t6 - t1) / 5.0, "abi_ms_six_iters": t6,
             "samples_ms": {"numiter1": t[1][1:], "numiter6": t[6]},
+            "split_ms": {k_: min(v) for k_, v in split.items()},
             "note": f"run_poismf(method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}) on the workload matrix through "
                     "ctypes: min of 3 calls each with numiter 1 and 6 (the process's first call, which also pays device "
                     "initialisation, is dropped); per_extra_iter = (min t6 - min t1) / 5"}
@@ -489,7 +520,7 @@ def main():
             "results_finite": res["finite"],
             "results_alive": dict(res["alive"], note="results_finite = no NaN / inf anywhere; it does NOT mean the factors are alive: with the "
                                   "reference's Python defaults for pg (l2 1e9, step 1e-7) the reference's own arithmetic drives this matrix's "
-                                  "factors to exact zeros within the first sweeps (DESIGN.md 6.1) -- A/B_nonzero_frac say how much is left; the "
+                                  "factors to exact zeros within the first sweeps (DESIGN.md 6.2) -- A/B_nonzero_frac say how much is left; the "
                                   "by_config.pg_finite line times the same kernels on factors that stay positive"),
         }
         if extra:

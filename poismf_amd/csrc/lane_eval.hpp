@@ -33,7 +33,7 @@
 //
 // Instruction count of one gradient pass over a 128-nonzero tile, k = 50: 200 fp64 FMAs (dots + axpy), 144 swap-fold
 // instructions, 15 adds, ~60 for the two divisions, ~50 LDS operations -- ~470 against ~950 in the slot layout
-// (DESIGN.md section 6.1: 34 instructions per four-nonzero step, 16 of them v_accvgpr_read).
+// (DESIGN.md section 6.2: 34 instructions per four-nonzero step, 16 of them v_accvgpr_read).
 //
 // This is the reference's per-nonzero ddot + daxpy (ref: src/poismf.c:126-133 calc_grad_pgd, :194-208
 // calc_fun_single, :210-240 calc_grad_single[_w], :242-273 calc_fun_and_grad).

@@ -205,6 +205,10 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
             if (cls <= 1088) return { 1, 2, 1, 4, 0, 16 };   // 4 x (64 + 128 + 64 + 16) nonzeros: C3's item rows (Poisson(1000)) end here but for 0.3 %
         } else if (s_load == 50) {   // a set is 200 registers / 51 KB of LDS
             if (cls <= 64) return { 1, 0, 0, 1, 0 };
+            // (two such rows per CU: config C5's user rows of 65 .. ~95 nonzeros leave the streamed path; tuning knob
+            // POISMF_HIP_K100_LANE_MAX=<64|128>)
+            static const unsigned k100_max = getenv("POISMF_HIP_K100_LANE_MAX") ? (unsigned)atoi(getenv("POISMF_HIP_K100_LANE_MAX")) : 128u;
+            if (cls <= 128 && cls <= k100_max) return { 1, 0, 1, 1, 0 };
         }
     } else if (PMF_LANE_F32 && s_load == 13) {   // floats: a set is 52 registers, every set in architectural registers, two waves per SIMD
         if (method == POISMF_PG) {

@@ -765,6 +765,7 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
         } else if (s_load == 50) {
             switch (key) {
                 case 10010: return launch_lane<METHOD, 50, 1, 0, 0, 1>(stream, a, grid_mult);
+                case 10110: return launch_lane<METHOD, 50, 1, 0, 1, 1>(stream, a, grid_mult);
             }
         }
     } else {

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -1010,6 +1011,13 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             LaneShape ls = lane_shape_for(b.cls, g.s_load, pm);
             static const bool no_pair = getenv("POISMF_HIP_NO_PAIR") != nullptr;   // testing knob: one row stream per workgroup everywhere
             if (no_pair) ls.pair = 0;
+            // k = 100 fp64 rows of 65 .. 128 nonzeros: the lane instance with an LDS set serves the A half only.  Measured on config C5
+            // (scripts/probes/c5_halves.py, same box): A half 159.5 -> 142.9 ms with it, but the B half 234.6 -> 296.0 -- taking its 39 k
+            // such rows out of the streamed launch leaves that launch (23 k rows of 129 .. 8192 nonzeros beside the 60 giant rows) at 277 ms
+            // instead of 232 for the same evaluations; the short rows were the tail that kept its 784 wave slots busy while the long rows
+            // drained.  Which half a row belongs to never depends on the shard.  (POISMF_HIP_K100_LANE_B=1: on both halves)
+            static const bool k100_lane_b = getenv("POISMF_HIP_K100_LANE_B") != nullptr;
+            if (sizeof(real_t) == 8 && g.s_load == 50 && b.cls > 64 && which == 0 && !k100_lane_b) ls.waves = 0;
             if (ls.waves > 0) {
                 if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp && launches.back().lane_pair == ls.pair &&
                     launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)
@@ -1183,7 +1191,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         int rc = 1;
         // (with long rows on the second stream, the one-wave bins that follow go wherever less work is queued: on C5 the lane rows
         // run behind the giant rows on the second stream while the mid-length bin has the main one)
-        const int lane_stream = (forked && (fork_bins || any_long) && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
+        int lane_stream = (forked && (fork_bins || any_long) && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
+        static const int force_lane_stream = getenv("POISMF_HIP_LANE_STREAM") ? atoi(getenv("POISMF_HIP_LANE_STREAM")) : -1;   // tuning knob: 0 / 1 = every one-wave lane bin on the main / second stream
+        if (force_lane_stream >= 0 && forked && L.nw == 1 && L.lane_L > 0) lane_stream = force_lane_stream ? 1 : 0;
         hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
@@ -1425,7 +1435,9 @@ struct SigintScope {
 };
 
 // The outer alternation on a session whose factors are set (ref: src/poismf.c:506-608).  Returns 0, or 1 on a device error.
-int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t numiter)
+// after_first_b: called once, right after the FIRST B half has been launched (run_poismf uploads the A side's matrix then: that half needs
+// the CSC and the factors only, and the copy engine is idle while it runs)
+int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t numiter, const std::function<int()>* after_first_b = nullptr)
 {
     const int method = p.method;
     const real_t l2_reg = p.l2_reg;
@@ -1443,6 +1455,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
             if (poismf_hip_half_sweep(s, 0, &p, step_size, cnst_div, tn_stop ? &unchanged : nullptr)) return 1;
             if (tn_stop) stopped_earlyB = ((double)unchanged / (double)s->dimB) >= .95;  // ref: :401-403 (quirk Q7)
         }
+        if (it == 0 && after_first_b != nullptr && (*after_first_b)()) return 1;
         if (method == POISMF_PG) step_size *= 0.5;  // ref: :532-533
         HIP_TRY(hipStreamSynchronize(s->stream));
         if (g_should_stop) break;
@@ -1758,12 +1771,27 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     double t[5] = { 0, 0, 0, 0, 0 };
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6; };
     t[0] = now();
-    bool bad = poismf_hip_session_create(&s, device, nullptr, Xr, Xr_indptr, Xr_indices, Xc, Xc_indptr, Xc_indices, dimA, dimB, k, 0,
-                                         dimA, 0, dimB) != 0;
+    // The session is put together in the order the first iteration needs things: the B side's matrix (CSC) and the factors first; the A
+    // side's matrix (CSR: a third of the call's PCIe bytes) is uploaded -- pinned chunks, second stream -- and its rows are sorted while
+    // the first B half runs (round 4).  poismf_hip_session_create does the same two build_half calls back to back.
+    s = session_alloc(device, nullptr, dimA, dimB, k);
+    bool bad = s == nullptr;
+    bad = bad || build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, 0, dimB, device);
     t[1] = now();
     bad = bad || poismf_hip_session_set_factors(s, A, B);
     t[2] = now();
-    bad = bad || run_alternation(s, p, numiter);
+    double t_csr = 0;
+    const std::function<int()> upload_csr = [&]() -> int {
+        const double t0 = now();
+        HIP_TRY(hipSetDevice(device));
+        if (build_half(s->half[1], s->aux_stream, Xr, Xr_indptr, Xr_indices, dimA, dimB, 0, dimA, device)) return 1;
+        HIP_TRY(hipStreamSynchronize(s->aux_stream));
+        t_csr = now() - t0;
+        return 0;
+    };
+    static const bool no_overlap = getenv("POISMF_HIP_NO_UPLOAD_OVERLAP") != nullptr;   // testing knob: the whole matrix before anything runs
+    if (!bad && (no_overlap || numiter == 0)) bad = upload_csr() != 0;
+    bad = bad || run_alternation(s, p, numiter, (no_overlap || numiter == 0) ? nullptr : &upload_csr);
     t[3] = now();
     bad = bad || poismf_hip_session_get_factors(s, A, B);
     t[4] = now();
@@ -1773,8 +1801,9 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     }
     poismf_hip_session_destroy(s);
     if (verbose)
-        fprintf(stderr, "run_poismf: session (upload X, sort rows) %.2f ms, factors up %.2f ms, %zu iterations %.2f ms, factors down %.2f ms, "
-                        "teardown %.2f ms\n", t[1] - t[0], t[2] - t[1], numiter, t[3] - t[2], t[4] - t[3], now() - t[4]);
+        fprintf(stderr, "run_poismf: session + B side of X (upload, sort rows) %.2f ms, factors up %.2f ms, %zu iterations %.2f ms (of which the A "
+                        "side of X, uploaded under the first B half: %.2f ms), factors down %.2f ms, teardown %.2f ms\n", t[1] - t[0], t[2] - t[1],
+                numiter, t[3] - t[2], t_csr, t[4] - t[3], now() - t[4]);
     return sig.leave(ret_code, handle_interrupt);
 }
 

@@ -68,3 +68,40 @@ def test_sharded_generation_reproduces_the_one_shot_triplets():
         assert np.array_equal(u.row, t.row[m]) and np.array_equal(u.col, t.col[m]) and np.array_equal(u.data, t.data[m])
         seen |= m
     assert seen.all()
+
+
+def test_traffic_is_quoted_only_for_this_trees_kernels(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/hbm_traffic.json (separate rocprofv3 --pmc passes, scripts/profile_round.sh); bench.py quotes
+    it only while the file carries the hash of THIS tree's kernel sources + flags, and says where the number came from."""
+    import json
+    b = _bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    good = b.build._source_hash()
+    (prof / "hbm_traffic.json").write_text(json.dumps({"round": "rXX", "source_hash": good, "C4_pg_maxupd10_f32": 5.0e10}))
+    v, src = b.traffic_from_profiles("C4_pg_maxupd10_f32")
+    assert v == 5.0e10 and "rXX" in src and good[:12] in src
+    assert b.traffic_from_profiles("C4_cg_maxupd5_f64")[0] is None            # no such entry
+    (prof / "hbm_traffic.json").write_text(json.dumps({"round": "rXX", "source_hash": "0" * 64, "C4_pg_maxupd10_f32": 5.0e10}))
+    v, src = b.traffic_from_profiles("C4_pg_maxupd10_f32")
+    assert v is None and "not quoted" in src
+
+
+def test_valu_roofline_counts_the_references_flops():
+    """roofline.valu: a PG pass is one gradient (4k+1 flops per nonzero), CG one gradient per iteration and one function value
+    (2k+25) per trial, TNC 4k+26 per evaluation, against the vector peak of the precision."""
+    b = _bench()
+
+    class J:
+        k, use_float = 50, True
+    res = dict(method="pg", psteps=2, ev_stats=[(0, 1000), (0, 3000)], dec_stats=None)
+    v = b.valu_block(J, res, sweep_ms=1.0)
+    assert v["flops_per_sweep"] == (1000 + 3000) / 2 * 201 and v["peak"] == 157.3
+    assert abs(v["achieved"] - v["flops_per_sweep"] / 1e-3 / 1e12) < 1e-9 and abs(v["frac"] - v["achieved"] / 157.3) < 1e-12
+    J.use_float = False
+    d = [dict(iterations=5, evaluations=9, nnz_iterations=500, nnz_evaluations=900)] * 2
+    v = b.valu_block(J, dict(method="cg", psteps=1, ev_stats=None, dec_stats=d), sweep_ms=2.0)
+    assert v["flops_per_sweep"] == 1000 * 201 + (1000 + 1800) * 125 and v["peak"] == 78.6
+    v = b.valu_block(J, dict(method="tncg", psteps=1, ev_stats=None, dec_stats=d), sweep_ms=2.0)
+    assert v["flops_per_sweep"] == 1800 * 226

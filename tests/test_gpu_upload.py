@@ -36,6 +36,9 @@ def test_staged_copies_leave_no_trace(prec, method, kw, tmp_path):
         "staged3": {"POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "3"},
         "staged7": {"POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "7"},
         "staged1": {"POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "1"},
+        # round 4: run_poismf uploads the A side's matrix on the second stream while the first B half runs; here the whole matrix first
+        "no_overlap": {"POISMF_HIP_NO_UPLOAD_OVERLAP": "1"},
+        "no_overlap_staged": {"POISMF_HIP_NO_UPLOAD_OVERLAP": "1", "POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "3"},
     }
     res = {}
     for tag, env in runs.items():
@@ -46,5 +49,5 @@ def test_staged_copies_leave_no_trace(prec, method, kw, tmp_path):
                        timeout=600)
         res[tag] = np.load(out)
     assert np.isfinite(res["plain"]).all() and res["plain"].any()
-    for tag in ("staged3", "staged7", "staged1"):
+    for tag in ("staged3", "staged7", "staged1", "no_overlap", "no_overlap_staged"):
         assert np.array_equal(res[tag], res["plain"]), tag
