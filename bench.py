@@ -282,6 +282,7 @@ def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
     t1, t6 = min(t[1][1:]), min(t[6])
     # where a call's time goes: the same steps through the session entry points, each timed (min of 3): what run_poismf does inside
     split = {"session_create_upload_X_and_sort": [], "factors_up": [], "one_iteration": [], "factors_down": [], "destroy": []}
+    outA, outB = A0.copy(), B0.copy()   # (touched pages, as run_poismf's own in / out arrays are)
     for _ in range(3):
         t0 = time.perf_counter()
         sess = api.Session(csr, csc, dimA, dimB, K, use_float)
@@ -293,18 +294,20 @@ def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
             sess.sweep(prm, 1e-7)
         sess.kernel_time(0)   # (synchronises the session stream)
         tc = time.perf_counter()
-        sess.get_factors()
+        sess.get_factors(out=(outA, outB))
         td = time.perf_counter()
         sess.close()
         te = time.perf_counter()
         for name, dt in zip(split, (ta - t0, tb - ta, tc - tb, td - tc, te - td)):
             split[name].append(dt * 1e3)
     return {"abi_ms_first_iter": t1, "abi_ms_per_extra_iter": (t6 - t1) / 5.0, "abi_ms_six_iters": t6,
-            "samples_ms": {"numiter1": t[1][1:], "numiter6": t[6]},
+            "samples_ms": {"numiter1": t[1][1:], "numiter6": t[6]}, "first_call_ms": t[1][0],
             "split_ms": {k_: min(v) for k_, v in split.items()},
             "note": f"run_poismf(method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}) on the workload matrix through "
-                    "ctypes: min of 3 calls each with numiter 1 and 6 (the process's first call, which also pays device "
-                    "initialisation, is dropped); per_extra_iter = (min t6 - min t1) / 5"}
+                    "ctypes: min of 3 calls each with numiter 1 and 6; per_extra_iter = (min t6 - min t1) / 5.  The process's first run_poismf "
+                    "call (first_call_ms; the device is up by then, the blocks above ran first) also pays the pinned staging chunks and its hipMallocs; "
+                    "later calls find their device arrays in the library's list of released ones (devmem.hpp, "
+                    "POISMF_HIP_DEVICE_CACHE_MB) and their streams recycled"}
 
 
 _CPU_CACHE = {}

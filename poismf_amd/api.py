@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_create_coo", "poismf_hip_session_stream", "poismf_hip_session_factors_dirty", "poismf_hip_session_run",
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
     "poismf_hip_session_launch_profile", "poismf_hip_session_decisions", "poismf_hip_session_decision_stats", "poismf_hip_factors_multiple_decisions",
-    "poismf_hip_session_predict", "poismf_hip_session_topn", "poismf_hip_debug_row_eval",
+    "poismf_hip_session_predict", "poismf_hip_session_topn", "poismf_hip_debug_row_eval", "poismf_hip_release_cache",
 )
 
 
@@ -72,6 +72,8 @@ def load_library(use_float):
     lib.poismf_hip_session_decisions.restype = i
     lib.poismf_hip_session_decision_stats.argtypes = [vp, i, C.POINTER(C.c_ulonglong)]
     lib.poismf_hip_session_decision_stats.restype = i
+    lib.poismf_hip_release_cache.argtypes = []
+    lib.poismf_hip_release_cache.restype = None
     lib.predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
     lib.predict_multiple.restype = None
     lib.topN.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz, i]
@@ -432,10 +434,17 @@ class Session:
         if self.lib.poismf_hip_session_set_factors(self.h, _ptr(A), _ptr(B)):
             raise RuntimeError("poismf_hip_session_set_factors failed")
 
-    def get_factors(self):
+    def get_factors(self, out=None):
+        """(A, B) on the host; out = (A, B): into these C-contiguous arrays of the session's shapes and precision."""
         dt = np.float32 if self.use_float else np.float64
-        A = np.empty((self.dimA, self.k), dt)
-        B = np.empty((self.dimB, self.k), dt)
+        if out is not None:
+            A, B = out
+            for M, n in ((A, self.dimA), (B, self.dimB)):
+                if M.dtype != dt or M.shape != (n, self.k) or not M.flags.c_contiguous:
+                    raise ValueError("get_factors: out arrays must be C-contiguous, of the session's shapes and precision")
+        else:
+            A = np.empty((self.dimA, self.k), dt)
+            B = np.empty((self.dimB, self.k), dt)
         if self.lib.poismf_hip_session_get_factors(self.h, _ptr(A), _ptr(B)):
             raise RuntimeError("poismf_hip_session_get_factors failed")
         return A, B

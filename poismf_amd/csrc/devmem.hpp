@@ -14,11 +14,30 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
+#include <utility>
 #include <vector>
+
+// POISMF_HIP_TIMELINE=1: host wall-clock stamps of the set-up / copy phases on stderr (development aid; the stamps are taken where
+// the host is, asynchronous work may still be in flight behind them)
+inline void pmf_tl(const char* what)
+{
+    static const bool on = getenv("POISMF_HIP_TIMELINE") != nullptr;
+    if (!on) return;
+    static double first = 0, last = 0;
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t = (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+    if (what == nullptr || first == 0) first = last = t;
+    if (what != nullptr) fprintf(stderr, "[tl %8.2f +%7.2f] %s\n", t - first, t - last, what);
+    last = t;
+}
 
 inline bool pmf_async_alloc()
 {
@@ -26,18 +45,120 @@ inline bool pmf_async_alloc()
     return on;
 }
 
+// ---- the device arrays of finished sessions are kept for the next one (round 4) ---------------------------------------------------
+// run_poismf is a one-shot call: 2.5 GB of device arrays allocated, filled, used and freed per fit.  On this stack the freeing and
+// allocating is not only 2.5 ms of calls: it also leaves the copy engines busy behind the call's back (scripts/probes/stage_probe2.hip --
+// staged uploads over two DMA queues move 400 MB in 7.2-7.9 ms into arrays that stay allocated and in 11.5-12 ms, slower than one
+// queue, while arrays of that size are being allocated and freed around them).  So blocks of 1 MB and more go to a per-process list
+// when they are released and come back to the next request of exactly their size on their device: repeated fits on matrices of one
+// shape -- a hyper-parameter search, the bench's run_poismf leg -- find all their arrays there.  The list holds at most
+// POISMF_HIP_DEVICE_CACHE_MB (default 16384; 0 = off: plain hipMalloc / hipFree as before), oldest blocks leave first;
+// poismf_hip_release_cache() empties it; an allocation that fails empties it and tries again.  Blocks come back with their old
+// contents (as hipMalloc's are unspecified): nothing here may rely on fresh memory reading as zero.
+struct PmfDevCache {
+    struct Block { void* p; size_t bytes; int device; };
+    std::mutex mu;
+    std::vector<Block> idle;                                        // released, oldest first
+    std::unordered_map<void*, std::pair<size_t, int>> live;         // handed out, eligible to come back
+    size_t idle_bytes = 0;
+    static constexpr size_t LEAST = (size_t)1 << 20;
+    static size_t limit()
+    {
+        static const size_t v = [] {
+            const char* e = getenv("POISMF_HIP_DEVICE_CACHE_MB");
+            return (size_t)(e ? atoll(e) : 16384) << 20;
+        }();
+        return v;
+    }
+    // (mu held)
+    void drop_oldest_until(size_t room)
+    {
+        size_t n = 0;
+        while (n < idle.size() && idle_bytes > room) { (void)hipFree(idle[n].p); idle_bytes -= idle[n].bytes; n++; }
+        idle.erase(idle.begin(), idle.begin() + (long)n);
+    }
+};
+inline PmfDevCache& pmf_dev_cache()
+{
+    static PmfDevCache* c = new PmfDevCache();   // (never destroyed: no HIP calls from static destructors at exit)
+    return *c;
+}
+inline void pmf_release_cache()
+{
+    PmfDevCache& c = pmf_dev_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.drop_oldest_until(0);
+}
+
 template <class T> inline hipError_t pmf_alloc(T** p, size_t bytes, hipStream_t stream)
 {
     void* q = nullptr;
-    const hipError_t e = pmf_async_alloc() ? hipMallocAsync(&q, bytes ? bytes : 16, stream) : hipMalloc(&q, bytes ? bytes : 16);
+    if (bytes == 0) bytes = 16;
+    if (pmf_async_alloc()) {
+        const hipError_t e = hipMallocAsync(&q, bytes, stream);
+        *p = (T*)q;
+        return e;
+    }
+    PmfDevCache& c = pmf_dev_cache();
+    const bool cached = bytes >= PmfDevCache::LEAST && PmfDevCache::limit() > 0;
+    int device = 0;
+    if (cached) {
+        if (hipGetDevice(&device) != hipSuccess) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (size_t i = c.idle.size(); i-- > 0;) {
+            if (c.idle[i].bytes == bytes && c.idle[i].device == device) {
+                q = c.idle[i].p;
+                c.idle_bytes -= bytes;
+                c.idle.erase(c.idle.begin() + (long)i);
+                c.live[q] = std::make_pair(bytes, device);
+                *p = (T*)q;
+                return hipSuccess;
+            }
+        }
+    }
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e == hipErrorOutOfMemory) {   // make room: whatever the cache holds goes back to the driver first
+        (void)hipGetLastError();
+        pmf_release_cache();
+        q = nullptr;
+        e = hipMalloc(&q, bytes);
+    }
+    if (e == hipSuccess && cached) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.live[q] = std::make_pair(bytes, device);
+    }
     *p = (T*)q;
     return e;
 }
 inline void pmf_free(void* p, hipStream_t stream)
 {
     if (p == nullptr) return;
-    if (pmf_async_alloc()) (void)hipFreeAsync(p, stream);
-    else (void)hipFree(p);   // waits for the device: nothing can still be using the block
+    if (pmf_async_alloc()) { (void)hipFreeAsync(p, stream); return; }
+    PmfDevCache& c = pmf_dev_cache();
+    {
+        std::unique_lock<std::mutex> lk(c.mu);
+        const auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const size_t bytes = it->second.first;
+            const int device = it->second.second;
+            c.live.erase(it);
+            if (bytes <= PmfDevCache::limit()) {
+                lk.unlock();
+                // what hipFree does implicitly and the callers rely on: nothing on the device can still be using the block
+                int cur = -1;
+                (void)hipGetDevice(&cur);
+                if (cur != device) (void)hipSetDevice(device);
+                (void)hipDeviceSynchronize();
+                if (cur != device && cur >= 0) (void)hipSetDevice(cur);
+                lk.lock();
+                c.drop_oldest_until(PmfDevCache::limit() - bytes);
+                c.idle.push_back({ p, bytes, device });
+                c.idle_bytes += bytes;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);   // waits for the device: nothing can still be using the block
 }
 
 // Host <-> device copies of CALLER-OWNED (pageable) memory: drain the stream, then copy synchronously; kernels launched
@@ -61,7 +182,10 @@ inline hipError_t pmf_download(void* dst, const void* src, size_t bytes, hipStre
 // thread doing the copying; here a few host threads fill pinned chunks -- copying values, or NARROWING indices on the way, so that
 // half of the index bytes never cross PCIe -- while the DMA engine drains the chunks filled before (hipMemcpyAsync from pinned
 // memory, ~50 GB/s).  Each thread owns a contiguous part of the array and two chunks; an event per chunk says when it may be
-// refilled.  One pool PER DEVICE (round 4: the per-device threads of a multi-GPU run_poismf each stage through their own; with one
+// refilled.  Round 4: TWO DMA queues -- the caller's stream and the pool's own side stream, threads alternating between them, the
+// side stream fenced against the caller's by an event at either end: one queue moves 4 MB chunks at 41-44 GB/s, two at 53-55
+// (scripts/probes/stage_probe.hip: 400 MB in 10.1 -> 7.9 ms with the narrowing fill; 16 MB chunks, 16 threads or four queues add nothing).
+// One pool PER DEVICE (round 4: the per-device threads of a multi-GPU run_poismf each stage through their own; with one
 // pool per process seven of eight set-ups fell back to the pageable path); one staged copy at a time per device, a caller that
 // finds its device's pool busy takes the plain path.
 struct PmfPinPool {
@@ -70,17 +194,30 @@ struct PmfPinPool {
     std::mutex busy;
     void* buf[2 * THREADS_MAX] = {};
     hipEvent_t ev[2 * THREADS_MAX] = {};
+    hipStream_t side = nullptr;          // the second DMA queue
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool ready = false, failed = false;
-    // (called with `busy` held and the device current: the events belong to that device)
+    // (called with `busy` held and the device current: the events and the side stream belong to that device)
     bool prepare()
     {
         if (ready || failed) return ready;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&ev_end, hipEventDisableTiming) != hipSuccess) {
+            if (ev_begin != nullptr) (void)hipEventDestroy(ev_begin);
+            if (side != nullptr) (void)hipStreamDestroy(side);
+            side = nullptr; ev_begin = ev_end = nullptr;
+            (void)hipGetLastError();
+            failed = true;
+            return false;
+        }
         for (int i = 0; i < 2 * THREADS_MAX; i++) {
             if (hipHostMalloc(&buf[i], CHUNK, hipHostMallocDefault) != hipSuccess) buf[i] = nullptr;
             if (buf[i] == nullptr || hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
                 // nothing half-built stays behind: this device copies through the plain path from now on
                 if (buf[i] != nullptr) { (void)hipHostFree(buf[i]); buf[i] = nullptr; }
                 for (int j = 0; j < i; j++) { (void)hipHostFree(buf[j]); buf[j] = nullptr; (void)hipEventDestroy(ev[j]); }
+                (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end); (void)hipStreamDestroy(side);
+                side = nullptr; ev_begin = ev_end = nullptr;
                 (void)hipGetLastError();
                 failed = true;
                 return false;
@@ -107,6 +244,12 @@ inline int pmf_host_threads()
     }();
     return n;
 }
+// the second DMA queue joins in unless POISMF_HIP_ONE_DMA_QUEUE is set (testing knob)
+inline bool pmf_two_queues()
+{
+    static const bool off = getenv("POISMF_HIP_ONE_DMA_QUEUE") != nullptr;
+    return !off;
+}
 // arrays below 16 MB are not worth the threads (testing knobs: POISMF_HIP_NO_STAGED_UPLOAD, POISMF_HIP_STAGED_MIN_BYTES)
 inline bool pmf_staged_wanted(size_t bytes)
 {
@@ -127,9 +270,17 @@ template <class Fill> inline hipError_t pmf_upload_staged(void* dst, size_t n, s
     const int nt = pmf_host_threads();
     const size_t per_chunk = PmfPinPool::CHUNK / item;
     std::vector<hipError_t> err((size_t)nt, hipSuccess);
+    // odd threads copy on the side queue, which starts behind everything `stream` holds now and which `stream` waits for at the end
+    const bool two = pmf_two_queues() && nt > 1;
+    if (two) {
+        hipError_t e = hipEventRecord(pool.ev_begin, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pool.side, pool.ev_begin, 0);
+        if (e != hipSuccess) return e;
+    }
     auto work = [&](int t) {
         if (hipSetDevice(device) != hipSuccess) { err[(size_t)t] = hipErrorInvalidDevice; return; }
         const size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        const hipStream_t q = (two && (t & 1)) ? pool.side : stream;
         int b = 0;
         for (size_t i = lo; i < hi; i += per_chunk, b ^= 1) {
             const size_t cnt = hi - i < per_chunk ? hi - i : per_chunk;
@@ -137,9 +288,9 @@ template <class Fill> inline hipError_t pmf_upload_staged(void* dst, size_t n, s
             hipError_t e = hipEventSynchronize(pool.ev[slot]);   // (a never-recorded event is complete)
             if (e == hipSuccess) {
                 fill(pool.buf[slot], i, cnt);
-                e = hipMemcpyAsync((char*)dst + i * item, pool.buf[slot], cnt * item, hipMemcpyHostToDevice, stream);
+                e = hipMemcpyAsync((char*)dst + i * item, pool.buf[slot], cnt * item, hipMemcpyHostToDevice, q);
             }
-            if (e == hipSuccess) e = hipEventRecord(pool.ev[slot], stream);
+            if (e == hipSuccess) e = hipEventRecord(pool.ev[slot], q);
             if (e != hipSuccess) { err[(size_t)t] = e; return; }
         }
     };
@@ -147,6 +298,11 @@ template <class Fill> inline hipError_t pmf_upload_staged(void* dst, size_t n, s
     for (int t = 1; t < nt; t++) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
+    if (two) {   // (also after a failure: `stream` must not run ahead of copies still queued on the side)
+        hipError_t e = hipEventRecord(pool.ev_end, pool.side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, pool.ev_end, 0);
+        if (e != hipSuccess) return e;
+    }
     for (hipError_t e : err) if (e != hipSuccess) return e;
     return hipSuccess;   // (in stream order; the chunks stay owned by the pool until their events complete)
 }
@@ -164,13 +320,20 @@ template <class Take> inline hipError_t pmf_download_staged(const void* src, siz
     const int nt = pmf_host_threads();
     const size_t per_chunk = PmfPinPool::CHUNK / item;
     std::vector<hipError_t> err((size_t)nt, hipSuccess);
+    const bool two = pmf_two_queues() && nt > 1;
+    if (two) {   // the side queue starts behind whatever on `stream` produces the data
+        hipError_t e = hipEventRecord(pool.ev_begin, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pool.side, pool.ev_begin, 0);
+        if (e != hipSuccess) return e;
+    }
     auto work = [&](int t) {
         if (hipSetDevice(device) != hipSuccess) { err[(size_t)t] = hipErrorInvalidDevice; return; }
         const size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        const hipStream_t q = (two && (t & 1)) ? pool.side : stream;
         auto issue = [&](size_t i, int b) -> hipError_t {
             const size_t cnt = hi - i < per_chunk ? hi - i : per_chunk;
-            hipError_t e = hipMemcpyAsync(pool.buf[2 * t + b], (const char*)src + i * item, cnt * item, hipMemcpyDeviceToHost, stream);
-            return e != hipSuccess ? e : hipEventRecord(pool.ev[2 * t + b], stream);
+            hipError_t e = hipMemcpyAsync(pool.buf[2 * t + b], (const char*)src + i * item, cnt * item, hipMemcpyDeviceToHost, q);
+            return e != hipSuccess ? e : hipEventRecord(pool.ev[2 * t + b], q);
         };
         hipError_t e = hipEventSynchronize(pool.ev[2 * t]);   // (an upload's chunk may still be draining)
         if (e == hipSuccess) e = hipEventSynchronize(pool.ev[2 * t + 1]);
@@ -187,7 +350,7 @@ template <class Take> inline hipError_t pmf_download_staged(const void* src, siz
     for (int t = 1; t < nt; t++) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
-    for (hipError_t e : err) if (e != hipSuccess) return e;
+    for (hipError_t e : err) if (e != hipSuccess) { if (two) (void)hipStreamSynchronize(pool.side); return e; }
     return hipSuccess;   // (complete: every chunk was waited for)
 }
 // A plain array either way, staged when it can be.

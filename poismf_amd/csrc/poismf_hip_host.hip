@@ -329,36 +329,48 @@ unsigned length_class(unsigned n)
 // h.d_indptr (shard-local, nloc + 1), h.d_indices, h.d_values are on the device: per segment, sort the rows by length
 // (longest first, equal lengths in row order), build the row descriptors on the device and the length bins on the host
 // (from the sorted lengths: 4 bytes per row come back over PCIe, the only host work left is one linear scan).
-int finish_half(Half& h, hipStream_t stream, int nseg = 1)
+// In two steps, so that a caller can put other work (run_poismf: the factors' upload) between the launches and the one place that
+// waits for them.
+struct HalfPending { unsigned* d_len = nullptr; unsigned* d_flag = nullptr; };
+int finish_half_launch(Half& h, hipStream_t stream, HalfPending& pend, int nseg = 1)
 {
     const size_t nloc = h.row_end - h.row_begin;
-    unsigned* d_len = nullptr;
     if (h.d_perm == nullptr) HIP_TRY(pmf_alloc(&h.d_perm, sizeof(unsigned) * (nloc ? nloc : 1), stream));
     if (h.d_desc == nullptr) HIP_TRY(pmf_alloc(&h.d_desc, sizeof(RowDesc) * (nloc ? nloc : 1), stream));
     h.segs.clear();
     nseg = std::max(nseg, 1);   // as asked (segments of a short shard may be empty): every rank cuts its shard the same way
     if (nloc == 0) { for (int j = 0; j < nseg; j++) h.segs.push_back({ 0u, 0u, {} }); return 0; }
-    HIP_TRY(pmf_alloc(&d_len, sizeof(unsigned) * nloc, stream));
+    HIP_TRY(pmf_alloc(&pend.d_len, sizeof(unsigned) * nloc, stream));
     for (int j = 0; j < nseg; j++) {
         const size_t lo = nloc * (size_t)j / (size_t)nseg, hi = nloc * (size_t)(j + 1) / (size_t)nseg;   // == dist.segment_of
         h.segs.push_back({ (unsigned)lo, (unsigned)hi, {} });
-        if (hi > lo && poismf_hip_device_sort_rows(h.d_indptr + lo, hi - lo, (unsigned)lo, h.d_perm + lo, d_len + lo, stream)) { pmf_free(d_len, stream); return 1; }
+        if (hi > lo && poismf_hip_device_sort_rows(h.d_indptr + lo, hi - lo, (unsigned)lo, h.d_perm + lo, pend.d_len + lo, stream)) {
+            pmf_free(pend.d_len, stream);
+            pend.d_len = nullptr;
+            return 1;
+        }
     }
     const unsigned grid = (unsigned)std::min<size_t>((nloc + 255) / 256, 2048);
     hipLaunchKernelGGL(row_desc_kernel, dim3(grid), dim3(256), 0, stream, h.d_indptr, h.d_perm, nloc, h.d_desc);
     // are all stored values positive (Poisson counts)?  One pass over the values, the flag rides in front of the lengths
-    unsigned* d_flag = nullptr;
-    HIP_TRY(pmf_alloc(&d_flag, sizeof(unsigned), stream));
-    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(unsigned), stream));
+    HIP_TRY(pmf_alloc(&pend.d_flag, sizeof(unsigned), stream));
+    HIP_TRY(hipMemsetAsync(pend.d_flag, 0, sizeof(unsigned), stream));
     if (h.nnz > 0)
-        hipLaunchKernelGGL(values_positive_kernel, dim3((unsigned)std::min<size_t>((h.nnz + 255) / 256, 2048)), dim3(256), 0, stream, h.d_values, h.nnz, d_flag);
+        hipLaunchKernelGGL(values_positive_kernel, dim3((unsigned)std::min<size_t>((h.nnz + 255) / 256, 2048)), dim3(256), 0, stream, h.d_values, h.nnz, pend.d_flag);
+    return 0;
+}
+int finish_half_collect(Half& h, hipStream_t stream, HalfPending& pend)
+{
+    const size_t nloc = h.row_end - h.row_begin;
+    if (nloc == 0) return 0;
     std::vector<unsigned> len(nloc);
-    hipError_t e = pmf_download(len.data(), d_len, sizeof(unsigned) * nloc, stream);
+    hipError_t e = pmf_download(len.data(), pend.d_len, sizeof(unsigned) * nloc, stream);
     unsigned not_positive = 1;
-    if (e == hipSuccess) e = pmf_download(&not_positive, d_flag, sizeof(unsigned), stream);
+    if (e == hipSuccess) e = pmf_download(&not_positive, pend.d_flag, sizeof(unsigned), stream);
     h.x_positive = not_positive == 0;
-    pmf_free(d_flag, stream);
-    pmf_free(d_len, stream);
+    pmf_free(pend.d_flag, stream);
+    pmf_free(pend.d_len, stream);
+    pend = HalfPending();
     HIP_TRY(e);
     for (auto& sg : h.segs) {
         for (size_t i = sg.row_lo; i < sg.row_hi; i++) {
@@ -370,11 +382,18 @@ int finish_half(Half& h, hipStream_t stream, int nseg = 1)
     }
     return 0;
 }
+int finish_half(Half& h, hipStream_t stream, int nseg = 1)
+{
+    HalfPending pend;
+    if (finish_half_launch(h, stream, pend, nseg)) { pmf_free(pend.d_flag, stream); pmf_free(pend.d_len, stream); return 1; }
+    return finish_half_collect(h, stream, pend);
+}
 
 // Upload rows [r0, r1) of a host CSR (size_t indices) with shard-local pointers; the indices are narrowed to u32 on
 // the device (the binding rejects dimensions above INT_MAX, ref: poismf_c_wrapper.pxi:78-80).
+// (pend != nullptr: the row sort is launched but not waited for -- the caller owes a finish_half_collect)
 int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* indptr, const sparse_ix* indices,
-               size_t dimM, size_t dimF, size_t r0, size_t r1, int device = 0)
+               size_t dimM, size_t dimF, size_t r0, size_t r1, int device = 0, HalfPending* pend = nullptr)
 {
     h.dimM = dimM; h.dimF = dimF; h.row_begin = r0; h.row_end = r1;
     const size_t nloc = r1 - r0;
@@ -383,6 +402,7 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     HIP_TRY(pmf_alloc(&h.d_indptr, sizeof(unsigned long long) * (nloc + 1), stream));
     HIP_TRY(pmf_alloc(&h.d_indices, sizeof(unsigned) * (h.nnz ? h.nnz : 1), stream));
     HIP_TRY(pmf_alloc(&h.d_values, sizeof(real_t) * (h.nnz ? h.nnz : 1), stream));
+    pmf_tl("half: device arrays allocated");
     if constexpr (sizeof(sparse_ix) == sizeof(unsigned long long)) {
         // C / Python ABI: size_t indices go up as they are and are narrowed to u32 by a kernel
         HIP_TRY(pmf_upload(h.d_indptr, indptr + r0, sizeof(unsigned long long) * (nloc + 1), stream));
@@ -397,6 +417,7 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
                 for (size_t i = 0; i < cnt; i++) o[i] = (unsigned)q[i];
             });
             if (se != hipSuccess && se != hipErrorNotReady) HIP_TRY(se);
+            pmf_tl("half: row pointers up, indices narrowed and handed to the DMA queue");
         }
         if (h.nnz && se != hipSuccess) {
             unsigned long long* d_wide = nullptr;
@@ -426,7 +447,14 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
         if (se == hipErrorNotReady) HIP_TRY(pmf_upload(h.d_values, val + base, sizeof(real_t) * h.nnz, stream));
         else HIP_TRY(se);
     }
-    return finish_half(h, stream);
+    pmf_tl("half: values handed to the DMA queue");
+    if (pend != nullptr) {
+        if (finish_half_launch(h, stream, *pend)) { pmf_free(pend->d_flag, stream); pmf_free(pend->d_len, stream); *pend = HalfPending(); return 1; }
+        return 0;
+    }
+    const int bad = finish_half(h, stream);
+    pmf_tl("half: rows sorted, lengths back, bins cut");
+    return bad;
 }
 
 bool prefetch_enabled()
@@ -729,6 +757,9 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     if (own) release_stream(s->device, own);
     delete s;
 }
+
+// the device arrays kept from finished sessions (devmem.hpp) go back to the driver
+void poismf_hip_release_cache(void) { pmf_release_cache(); }
 
 // Whoever asks for the device pointers may write through them: the padded gather copies are re-derived afterwards.
 real_t* poismf_hip_session_A(poismf_hip_session* s) { s->padded_fresh[1] = false; return s->dA; }
@@ -1455,9 +1486,11 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
             if (poismf_hip_half_sweep(s, 0, &p, step_size, cnst_div, tn_stop ? &unchanged : nullptr)) return 1;
             if (tn_stop) stopped_earlyB = ((double)unchanged / (double)s->dimB) >= .95;  // ref: :401-403 (quirk Q7)
         }
+        if (it == 0) pmf_tl("first B half launched");
         if (it == 0 && after_first_b != nullptr && (*after_first_b)()) return 1;
         if (method == POISMF_PG) step_size *= 0.5;  // ref: :532-533
         HIP_TRY(hipStreamSynchronize(s->stream));
+        if (it == 0) pmf_tl("first B half done");
         if (g_should_stop) break;
 
         // ---- A half ----
@@ -1467,6 +1500,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
             if (tn_stop) stopped_earlyA = ((double)unchanged / (double)s->dimA) >= .95;
         }
         HIP_TRY(hipStreamSynchronize(s->stream));
+        if (it == 0) pmf_tl("first A half done");
         if (stopped_earlyA && stopped_earlyB) break;
     }
     return team_check(s);
@@ -1774,11 +1808,18 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     // The session is put together in the order the first iteration needs things: the B side's matrix (CSC) and the factors first; the A
     // side's matrix (CSR: a third of the call's PCIe bytes) is uploaded -- pinned chunks, second stream -- and its rows are sorted while
     // the first B half runs (round 4).  poismf_hip_session_create does the same two build_half calls back to back.
+    pmf_tl(nullptr);
     s = session_alloc(device, nullptr, dimA, dimB, k);
+    pmf_tl("session allocated (factors, streams)");
     bool bad = s == nullptr;
-    bad = bad || build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, 0, dimB, device);
+    HalfPending pendB;   // (the B side's row sort runs on the device while the host threads stage the factors)
+    bad = bad || build_half(s->half[0], s->stream, Xc, Xc_indptr, Xc_indices, dimB, dimA, 0, dimB, device, &pendB);
     t[1] = now();
     bad = bad || poismf_hip_session_set_factors(s, A, B);
+    pmf_tl("factors handed to the DMA queue");
+    if (!bad) bad = finish_half_collect(s->half[0], s->stream, pendB) != 0;
+    else if (s != nullptr) { pmf_free(pendB.d_flag, s->stream); pmf_free(pendB.d_len, s->stream); }
+    pmf_tl("B side: lengths back, bins cut");
     t[2] = now();
     double t_csr = 0;
     const std::function<int()> upload_csr = [&]() -> int {
@@ -1793,13 +1834,16 @@ int run_poismf(real_t* A, real_t* Xr, sparse_ix* Xr_indptr, sparse_ix* Xr_indice
     if (!bad && (no_overlap || numiter == 0)) bad = upload_csr() != 0;
     bad = bad || run_alternation(s, p, numiter, (no_overlap || numiter == 0) ? nullptr : &upload_csr);
     t[3] = now();
+    pmf_tl("iterations done");
     bad = bad || poismf_hip_session_get_factors(s, A, B);
+    pmf_tl("factors back");
     t[4] = now();
     if (bad) {
         pmf_report_failure();   // "Error: out of memory." (ref: :501) only when it was one
         ret_code = 1;
     }
     poismf_hip_session_destroy(s);
+    pmf_tl("session destroyed");
     if (verbose)
         fprintf(stderr, "run_poismf: session + B side of X (upload, sort rows) %.2f ms, factors up %.2f ms, %zu iterations %.2f ms (of which the A "
                         "side of X, uploaded under the first B half: %.2f ms), factors down %.2f ms, teardown %.2f ms\n", t[1] - t[0], t[2] - t[1],

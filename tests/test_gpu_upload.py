@@ -39,6 +39,8 @@ def test_staged_copies_leave_no_trace(prec, method, kw, tmp_path):
         # round 4: run_poismf uploads the A side's matrix on the second stream while the first B half runs; here the whole matrix first
         "no_overlap": {"POISMF_HIP_NO_UPLOAD_OVERLAP": "1"},
         "no_overlap_staged": {"POISMF_HIP_NO_UPLOAD_OVERLAP": "1", "POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "3"},
+        # the staged copies alternate between two DMA queues (the session's stream and the pool's side stream); here all on the first
+        "one_queue": {"POISMF_HIP_ONE_DMA_QUEUE": "1", "POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "7"},
     }
     res = {}
     for tag, env in runs.items():
@@ -49,5 +51,41 @@ def test_staged_copies_leave_no_trace(prec, method, kw, tmp_path):
                        timeout=600)
         res[tag] = np.load(out)
     assert np.isfinite(res["plain"]).all() and res["plain"].any()
-    for tag in ("staged3", "staged7", "staged1", "no_overlap", "no_overlap_staged"):
+    for tag in ("staged3", "staged7", "staged1", "no_overlap", "no_overlap_staged", "one_queue"):
         assert np.array_equal(res[tag], res["plain"]), tag
+
+
+CHILD_CACHE = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from tests import helpers as H
+from tests.test_gpu_parity import gpu_run
+from poismf_amd import api
+outs = []
+# the same shape three times (the second and third calls find every large array in the cache, with the previous call's contents in
+# it), another shape in between (its arrays join the list), a third precision-independent shape after an explicit release
+for dimA, dimB, nnz, seed in ((30000, 9000, 1500000, 21), (30000, 9000, 1500000, 22), (12000, 20000, 900000, 23), (30000, 9000, 1500000, 21)):
+    csr, csc, A0, B0 = H.small_problem(dimA, dimB, nnz, 50, False, seed=seed, powerlaw=True)
+    A, B, _ = gpu_run(csr, csc, A0, B0, "cg", 2, 50)
+    outs.append(np.concatenate([A.ravel(), B.ravel()]))
+    if seed == 23:
+        api.load_library(False).poismf_hip_release_cache()
+np.save({out!r}, np.concatenate(outs))
+"""
+
+
+def test_kept_device_arrays_leave_no_trace(tmp_path):
+    """devmem.hpp keeps the device arrays of finished calls for the next call of the same sizes: same bits as with the list off, and
+    the same problem gives the same bits the first and the last time."""
+    res = {}
+    for tag, env in {"kept": {}, "off": {"POISMF_HIP_DEVICE_CACHE_MB": "0"}, "tiny": {"POISMF_HIP_DEVICE_CACHE_MB": "40"}}.items():
+        out = str(tmp_path / f"{tag}.npy")
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", CHILD_CACHE.format(root=ROOT, out=out)], check=True, env=e, cwd=ROOT, timeout=600)
+        res[tag] = np.load(out)
+    assert np.isfinite(res["off"]).all() and res["off"].any()
+    assert np.array_equal(res["kept"], res["off"]) and np.array_equal(res["tiny"], res["off"])
+    n = (30000 + 9000) * 50
+    assert np.array_equal(res["kept"][:n], res["kept"][-n:])           # first and last call: the same problem
+    assert not np.array_equal(res["kept"][:n], res["kept"][n:2 * n])   # (and the second one is another)
