@@ -1127,7 +1127,11 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     static const bool static_rows = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;  // testing knob
     const bool dynamic = !is_pg && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
-    if (dynamic) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
+    // PG's multi-wave lane launches: 0 = one row per workgroup (the default, below), 1 = persistent workgroups pulling rows from the queue,
+    // 2 = persistent workgroups, rows dealt out statically (rounds 2-4a)      (tuning knob)
+    static const int pg_lane_rows = getenv("POISMF_HIP_PG_LANE_ROWS") ? atoi(getenv("POISMF_HIP_PG_LANE_ROWS")) : 0;
+    const bool pg_queue = is_pg && pg_lane_rows == 1 && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
+    if (dynamic || pg_queue) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
     // the few workgroup-per-row launches of the power-law tail occupy a few dozen CUs for a long time: run them on a
     // second stream beside the other bins (fork after the column sums, join before anything reads the result)
     // Several launches per half: they also alternate between the two streams (each to the one with less work queued so
@@ -1172,7 +1176,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             snprintf(lname, sizeof lname, "%s", txt);
             if (char* sp = strstr(lname, " rows=")) *sp = 0;
         }
-        a.queue = dynamic ? s->d_queue + launch_no : nullptr;
+        a.queue = (dynamic || (pg_queue && L.lane_L > 0 && L.nw > 1)) ? s->d_queue + launch_no : nullptr;
         launch_no++;
         a.perm_begin = L.begin;
         a.nrows = L.count;
@@ -1217,6 +1221,13 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         static const unsigned team_spin = getenv("POISMF_HIP_TEAM_SPIN_LIMIT") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_TEAM_SPIN_LIMIT"))) : TEAM_SPIN_LIMIT;   // testing knob
         a.team_spin = team_spin;
         unsigned grid_mult = one_wave_reg ? 32 : 2;
+        // PG on the multi-wave lane kernel: ONE ROW PER WORKGROUP, the hardware dispatcher hands them out.  Persistent workgroups that
+        // walk rows r, r + grid, .. keep the whole chip in step -- every CU gathers at the same time, then every CU computes -- and a
+        // launch is the sum of the two (section 6.0); workgroups that start whenever a slot frees drift apart and the gathers of some
+        // run under the passes of others.  C4 matrix, PG(10), the 78 715 item rows of 513 .. 1024 nonzeros: grid = 2 / 4 / 8 / 16 / 64
+        // workgroups per slot 4.28 / 4.13 / 4.08 / 4.09 / 4.39 ms, one row per workgroup 3.87 ms.  (Not for CG / TNCG, whose rows differ
+        // in cost and come from the queue: CG fp32 B half 11.25 -> 13.17 ms; not for the eight-wave register kernel: 1.83 -> 1.90.)
+        if (is_pg && L.lane_L > 0 && L.nw > 1 && pg_lane_rows == 0) grid_mult = 1u << 20;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
         int rc = 1;
