@@ -235,7 +235,7 @@ struct poismf_hip_session {
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
     unsigned* d_arrive = nullptr;           // workgroups of the forked long-row launch that have started (half_sweep_impl)
-    bool no_hold_back = false;              // hipStreamWaitValue32 / WriteValue32 failed once: later half-sweeps launch without the hold-back
+    unsigned long long gate_budget = 200000;   // ticks of the wall clock the hold-back gate waits at most: 2 ms (session_alloc)
     unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far
     real_t* d_team_backup = nullptr;        // the rows a team launch starts from (restored before its re-run)
     size_t team_backup_elems = 0;
@@ -293,6 +293,20 @@ __global__ __launch_bounds__(256) void team_restore_rows_kernel(real_t* M, real_
 __global__ void team_fold_err_kernel(unsigned* err)
 {
     if (err[0] != 0) { err[1] += 1; err[0] = 0; }
+}
+
+// The hold-back of a half-sweep's other bins behind its forked long-row launch (poismf_hip_half_sweep): one wave that returns when `goal`
+// workgroups of that launch have counted themselves in -- or when `budget` ticks of the constant-rate wall clock have passed, whichever is
+// first.  A BOUNDED wait on purpose: rounds 3-4a held the stream with hipStreamWaitValue32, and under `rocprofv3 --pmc` (dispatches serialised
+// by the tool) that wait kept the long-row launch from ever starting -- a counter pass over config C5 sat there until gpurun's limit
+// (one hour of round 4's GPU time).  This kernel gives up after 2 ms and the bins then run one after the other.
+__global__ void hold_back_gate_kernel(const unsigned* word, unsigned goal, unsigned long long budget)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < goal) {
+        if (wall_clock64() - t0 > budget) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
 }
 
 // flag |= 1 when some stored value is not > 0 (zero, negative, NaN)
@@ -588,6 +602,10 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) s->num_cu = n;
+    }
+    {
+        int khz = 0;   // constant-rate counter behind wall_clock64(): 100 MHz on this part
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) s->gate_budget = 2ull * (unsigned long long)khz;
     }
     s->stream = (hipStream_t)stream;
     auto fail = [&]() -> poismf_hip_session* { poismf_hip_session_destroy(s); return nullptr; };
@@ -1148,11 +1166,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // (a workgroup keeps its CU until the bin's queue is empty): whichever kernel reaches the chip first fills it, and on config C5
     // that was the mid-length bin -- the 60 giant rows then waited 260 ms for a CU and ran on their own afterwards (390 ms for what
     // takes 150 alone).  So every workgroup of the long-row launch counts itself in when it starts, and the main stream waits for
-    // that count (hipStreamWaitValue32: works on plain device memory here, scripts/probes/waitvalue_probe.hip) before it launches
-    // anything else.  Arrivals only ever grow, so a chip that cannot hold the whole launch at once delays the main stream, no more.
+    // that count (a one-wave gate kernel with a time limit, above; rounds 3-4a: hipStreamWaitValue32) before it launches anything else.
+    // Arrivals only ever grow, so a chip that cannot hold the whole launch at once delays the main stream by the gate's 2 ms, no more.
     static const bool no_arrive = getenv("POISMF_HIP_NO_ARRIVE_WAIT") != nullptr;   // testing knob
-    // (s->no_hold_back: hipStreamWaitValue32 failed once on this runtime / device -- the launches then simply share the chip as they come)
-    const bool hold_back = forked && any_long && !no_arrive && !s->no_hold_back;
+    const bool hold_back = forked && any_long && !no_arrive;
     if (hold_back) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, sizeof(unsigned), s->stream));
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
@@ -1221,12 +1238,13 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         static const unsigned team_spin = getenv("POISMF_HIP_TEAM_SPIN_LIMIT") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_TEAM_SPIN_LIMIT"))) : TEAM_SPIN_LIMIT;   // testing knob
         a.team_spin = team_spin;
         unsigned grid_mult = one_wave_reg ? 32 : 2;
-        // PG on the multi-wave lane kernel: ONE ROW PER WORKGROUP, the hardware dispatcher hands them out.  Persistent workgroups that
-        // walk rows r, r + grid, .. keep the whole chip in step -- every CU gathers at the same time, then every CU computes -- and a
-        // launch is the sum of the two (section 6.0); workgroups that start whenever a slot frees drift apart and the gathers of some
-        // run under the passes of others.  C4 matrix, PG(10), the 78 715 item rows of 513 .. 1024 nonzeros: grid = 2 / 4 / 8 / 16 / 64
-        // workgroups per slot 4.28 / 4.13 / 4.08 / 4.09 / 4.39 ms, one row per workgroup 3.87 ms.  (Not for CG / TNCG, whose rows differ
-        // in cost and come from the queue: CG fp32 B half 11.25 -> 13.17 ms; not for the eight-wave register kernel: 1.83 -> 1.90.)
+        // PG on the multi-wave lane kernel: ONE ROW PER WORKGROUP, the hardware dispatcher hands them out.  C4 matrix, PG(10), the 78 715 item
+        // rows of 513 .. 1024 nonzeros: persistent workgroups walking rows r, r + grid, .. at 2 / 4 / 8 / 16 / 64 workgroups per slot 4.28 /
+        // 4.13 / 4.08 / 4.09 / 4.39 ms; persistent workgroups on the queue 4.07; one row per workgroup 3.87 ms.  The queue's gain is balance
+        // (no workgroup owns a fixed share of the rows); the dispatcher's further gain is the ticket -- a persistent workgroup's row switch is
+        // four dependent round trips (ticket, descriptor, indices, gather) behind a barrier, a fresh workgroup has its row in blockIdx.
+        // (Not for CG / TNCG, whose rows differ in cost and want the longest-first queue: CG fp32 B half 11.25 -> 13.17 ms; not for the
+        // eight-wave register kernel, one workgroup per CU: 1.83 -> 1.90.)
         if (is_pg && L.lane_L > 0 && L.nw > 1 && pg_lane_rows == 0) grid_mult = 1u << 20;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
         const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
@@ -1258,17 +1276,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             rc = launch_one(p->method, o, a);
             if (!rc && a.arrive != nullptr) {
                 arrive_goal += std::min<unsigned>(grid, (unsigned)s->num_cu);   // (one eight-wave workgroup per CU)
-                // The way out of the wait below, whatever happens to the long-row launch: BEHIND it on its own stream the word is set to
-                // all ones, so the main stream is released at the latest when that launch has ended (it then ran before the other bins
-                // instead of beside them) -- no state of the chip leaves run_poismf waiting for workgroups that never arrive.
-                hipError_t we = hipStreamWriteValue32(long_stream, s->d_arrive, 0xffffffffu, 0);
-                if (we == hipSuccess) we = hipStreamWaitValue32(s->stream, s->d_arrive, arrive_goal, hipStreamWaitValueGte, 0xffffffffu);
-                if (we != hipSuccess) {
-                    // not supported here (or the stream is being captured): the error must not stay in the runtime's last-error slot
-                    // for the next launch's check to find, and the next half-sweeps do without the hold-back
-                    (void)hipGetLastError();
-                    s->no_hold_back = true;
-                }
+                // (hold_back_gate_kernel: returns when that many workgroups are on the chip, or after 2 ms)
+                hipLaunchKernelGGL(hold_back_gate_kernel, dim3(1), dim3(1), 0, s->stream, s->d_arrive, arrive_goal, s->gate_budget);
             }
             if (!rc && L.team > 1) {
                 // if the team launch gave up: rows back to where they started, the same rows on the streamed LDS kernel, note it

@@ -37,12 +37,11 @@ summaries() {
 summaries "$@"
 # config C5 (its own matrix, k = 100, tncg fp64) through scripts/run_config.py: 2 warm-up + 3 timed sweeps, no oracle sample.  Last, and
 # each counter pass under its own time limit: with counters on, dispatches are serialised, and this workload's B half forks its giant
-# rows onto a second stream (round 4's first profile round spent its last 20 minutes in the first of these passes).  The hold-back of
-# the other bins behind the forked launch is switched off for the counter passes.
+# rows onto a second stream and holds the other bins back until they are on the chip -- with hipStreamWaitValue32 (until mid round 4) the
+# first of these passes never ended.  The hold-back is a bounded gate kernel now; the limits stay.
 C5="python3 $R/scripts/run_config.py C5 --warmup 2 --sweeps 3 --sample 0"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_c5 -o kt --output-format csv -- $C5 > $OUT/kt_c5.log 2>&1
 grep '^{"config"' $OUT/kt_c5.log | tail -1 > $OUT/kt_c5_run_config.json
-export POISMF_HIP_NO_ARRIVE_WAIT=1
 timeout 420 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f_c5 -o pmc --output-format csv -- $C5 > $OUT/pmc_f_c5.log 2>&1 || echo "pmc_f_c5: rc $?" >> $OUT/c5_pmc_status.txt
 timeout 420 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w_c5 -o pmc --output-format csv -- $C5 > $OUT/pmc_w_c5.log 2>&1 || echo "pmc_w_c5: rc $?" >> $OUT/c5_pmc_status.txt
 timeout 420 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES -d $OUT/pmc_sq_c5 -o pmc --output-format csv -- $C5 > $OUT/pmc_sq_c5.log 2>&1 || echo "pmc_sq_c5: rc $?" >> $OUT/c5_pmc_status.txt
