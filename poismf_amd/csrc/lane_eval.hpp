@@ -250,7 +250,15 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // (only where four or more sets share each v_readlane: with the one to three sets of the CG / TNCG instances the 52 readlanes of an
     // evaluation cost more than 13 broadcast reads -- C2 CG fp32 2.20 -> 2.58 ms, TNCG fp32 12.6 -> 13.5 with it)
     static constexpr bool SPOINT = PMF_LANE_SPOINT && sizeof(T) == 4 && NC == 1 && LLT == 0 && LV_ >= 4;
+#ifndef PMF_LANE_PIPE_MW
+#define PMF_LANE_PIPE_MW 2   // sweep_rows' cross-row software pipeline (tickets two rows ahead, indices one) for MULTI-WAVE rows of this engine:
+                             // 0 = never, 1 = always (rounds 3-4a), 2 = under PG only.  Measured on the C4 matrix (variant builds, same box):
+                             // CG fp32 (eight waves per row) 20.20 -> 18.97 / 19.02 ms without it, B half 11.25 -> 10.25; CG fp64 (four waves)
+                             // 37.11 -> 36.83; TNCG fp32 119.1 -> 118.5; PG(10) fp32 3.85 -> 3.94 ms for the dominant launch.  A workgroup-wide
+                             // ticket is two barriers and an LDS round trip, and the next row's indices stay live across the whole solve.
+#endif
     static constexpr bool PIPELINED = true;
+    static constexpr int PIPE_MW = NW_ > 1 ? PMF_LANE_PIPE_MW : 1;   // (one-wave rows: always)
     static constexpr bool PARKS = false;
     static constexpr bool CACHED = true, MAY_CACHE = true, CACHED_GRAD = true;
     static constexpr int LS_BATCH = 1;

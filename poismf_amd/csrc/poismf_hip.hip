@@ -146,7 +146,7 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
         }
     }
 
-    if constexpr (EV::PIPELINED) {
+    if constexpr (EV::PIPELINED && (EV::PIPE_MW == 1 || (EV::PIPE_MW == 2 && METHOD == K_PG))) {
         // Software pipeline over the rows of this wave.  A row costs three dependent round trips to memory -- its
         // descriptor, its indices, the factor rows those name -- and the solver in between leaves the memory pipe idle.
         // Tickets (and descriptors) are fetched two rows ahead and the indices one row ahead, so that a row's gather

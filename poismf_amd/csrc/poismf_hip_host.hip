@@ -1241,8 +1241,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         // PG on the multi-wave lane kernel: ONE ROW PER WORKGROUP, the hardware dispatcher hands them out.  C4 matrix, PG(10), the 78 715 item
         // rows of 513 .. 1024 nonzeros: persistent workgroups walking rows r, r + grid, .. at 2 / 4 / 8 / 16 / 64 workgroups per slot 4.28 /
         // 4.13 / 4.08 / 4.09 / 4.39 ms; persistent workgroups on the queue 4.07; one row per workgroup 3.87 ms.  The queue's gain is balance
-        // (no workgroup owns a fixed share of the rows); the dispatcher's further gain is the ticket -- a persistent workgroup's row switch is
-        // four dependent round trips (ticket, descriptor, indices, gather) behind a barrier, a fresh workgroup has its row in blockIdx.
+        // (no workgroup owns a fixed share of the rows); what the dispatcher gains on top is measured, not explained (DESIGN.md section 6.0:
+        // neither the cross-row pipeline nor start delays account for it; the workgroup-wide ticket's two barriers per row remain).
         // (Not for CG / TNCG, whose rows differ in cost and want the longest-first queue: CG fp32 B half 11.25 -> 13.17 ms; not for the
         // eight-wave register kernel, one workgroup per CU: 1.83 -> 1.90.)
         if (is_pg && L.lane_L > 0 && L.nw > 1 && pg_lane_rows == 0) grid_mult = 1u << 20;

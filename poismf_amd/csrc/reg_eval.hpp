@@ -167,6 +167,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     static constexpr int NB = (S + G - 1) / G;    // batches of G steps = 64 nonzeros
     static constexpr int NW = NW_;
     static constexpr bool PIPELINED = true;       // sweep_rows prefetches the next row's indices during the solver
+    static constexpr int PIPE_MW = 1;             // (lane_eval.hpp: whether multi-wave rows take the pipeline depends on the solver)
     static constexpr bool FUSED_SUMS = false;     // (lane_eval.hpp reduces the solvers' groups of dot products together)
     static constexpr bool PREFETCH = false;       // (lane_eval.hpp can request the next row's tile while this one is solved)
     static constexpr int KP = G * NS * SN;        // elements of a (padded) k-vector in the cross-wave scratch

@@ -156,6 +156,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     static constexpr int SN = Slot<T>::N;
     static constexpr int NS = NC / SN;
     static constexpr bool PIPELINED = false;  // sweep_rows: no cross-row prefetch (the LDS tile has one set of index buffers)
+    static constexpr int PIPE_MW = 1;             // (lane_eval.hpp: whether multi-wave rows take the pipeline depends on the solver)
     static constexpr bool FUSED_SUMS = false;     // (lane_eval.hpp reduces the solvers' groups of dot products together)
     static constexpr bool PREFETCH = false;       // (lane_eval.hpp can request the next row's tile while this one is solved)
     static constexpr bool MAY_CACHE = true;   // cached CG line search where the launch geometry has room for it (pq_cap)
