@@ -89,3 +89,32 @@ def test_kept_device_arrays_leave_no_trace(tmp_path):
     n = (30000 + 9000) * 50
     assert np.array_equal(res["kept"][:n], res["kept"][-n:])           # first and last call: the same problem
     assert not np.array_equal(res["kept"][:n], res["kept"][n:2 * n])   # (and the second one is another)
+
+
+CHILD_HANDOUT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from tests import helpers as H
+from tests.test_gpu_parity import gpu_run
+# 300 item rows of ~800 nonzeros (PG fp32, k = 50: the four-wave lane launch) next to 4000 user rows of ~60 (one-wave register kernels)
+csr, csc, A0, B0 = H.small_problem(4000, 300, 240000, 50, True, seed=31)
+A, B, _ = gpu_run(csr, csc, A0, B0, "pg", 3, 50, l2_reg=1e3, step_size=1e-9, maxupd=10)
+np.save({out!r}, np.concatenate([A.ravel(), B.ravel()]))
+"""
+
+
+def test_pg_row_hand_out_leaves_no_trace(tmp_path):
+    """PG's multi-wave lane launches hand their rows out one per workgroup (round 4); persistent workgroups on the queue or with static shares
+    (POISMF_HIP_PG_LANE_ROWS = 1 / 2), another grid size or a start delay must give the same bits: a row's arithmetic depends on its length
+    class alone."""
+    res = {}
+    for tag, env in {"fresh": {}, "queue": {"POISMF_HIP_PG_LANE_ROWS": "1"}, "static": {"POISMF_HIP_PG_LANE_ROWS": "2"},
+                     "static_g7": {"POISMF_HIP_PG_LANE_ROWS": "2", "POISMF_HIP_GRID_MULT": "7"}, "stagger": {"POISMF_HIP_STAGGER": "5000"}}.items():
+        out = str(tmp_path / f"{tag}.npy")
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", CHILD_HANDOUT.format(root=ROOT, out=out)], check=True, env=e, cwd=ROOT, timeout=600)
+        res[tag] = np.load(out)
+    assert np.isfinite(res["fresh"]).all() and res["fresh"].any()
+    for tag in ("queue", "static", "static_g7", "stagger"):
+        assert np.array_equal(res[tag], res["fresh"]), tag
