@@ -395,6 +395,71 @@ def cpu_baseline(trip, method, use_float, maxupd, l2=None, step0=1e-7, iters=(1,
                       f"(the faster of {sorted(int(n) for n in _CPU_THREADS['tried'])}, bound close to cores) on {cpu}"}
 
 
+def _r(x, sig=4):
+    """numbers of the printed line carry `sig` significant digits (the full-precision object goes to bench_full.json)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{sig}g}")
+    except (TypeError, ValueError):
+        return x
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract's keys, the headline's two rooflines, the CPU baseline and one short entry per
+    line of the metric (`by_config`) -- no launch lists, no notes.  Round 4's line had grown to 35.7 KB and the driver, which keeps a
+    2 000-character tail, recorded `parsed: null`; everything else now goes to bench_full.json.  tests/test_bench_line.py holds this
+    function to < 2 000 characters on a recorded full object."""
+    rf = full.get("roofline") or {}
+    dom = rf.get("dominant_kernel") or {}
+    cb = full.get("cpu_baseline") or {}
+    cfg = full.get("config") or {}
+    out = {k_: full.get(k_) for k_ in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["value"] = _r(full.get("value"), 6)
+    out["ms_per_step"] = _r(full.get("ms_per_step"), 5)
+    sharding = str(cfg.get("sharding", "none"))
+    out["config"] = {"workload": cfg.get("workload"), "baseline_config": str(cfg.get("baseline_config", "")).split(":")[0],
+                     "sharding": sharding if len(sharding) <= 64 else sharding[:61] + "..."}
+    src = rf.get("traffic_source")
+    out["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                       "frac": _r(rf.get("frac")), "traffic": _r(rf.get("traffic")),
+                       "traffic_source": None if src is None else ("separate rocprofv3 --pmc run, profiles/hbm_traffic.json"
+                                                                   if rf.get("traffic") is not None else "stale: not quoted"),
+                       "dominant_kernel": {"kernel": dom.get("kernel"), "avg_ms": _r(dom.get("avg_ms")), "frac": _r(dom.get("frac"))},
+                       "valu": {"frac": _r((rf.get("valu") or {}).get("frac"))}}
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": "nnz/s", "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "seconds_per_sweep": _r(cb.get("seconds_per_sweep")),
+                               "sample": "whole workload matrix, run_poismf 2 iters minus 1, bound OpenMP threads"}
+    alive = full.get("results_alive") or {}
+    out["results_alive"] = {k_: _r(alive.get(k_)) for k_ in ("A_nonzero_frac", "B_nonzero_frac")}
+    byc_cpu = cb.get("by_config") or {}
+    byc = {}
+    for name, b in (rf.get("by_config") or {}).items():
+        e = {"ms": _r(b.get("ms_per_step")), "frac": _r(b.get("frac"), 3), "valu": _r(b.get("frac_valu"), 3)}
+        if name in byc_cpu:
+            e["cpu_s"] = _r(byc_cpu[name].get("seconds_per_sweep"), 3)
+        byc[name] = e
+    out["by_config"] = byc
+    abi = (full.get("extra") or {}).get("run_poismf_abi")
+    if abi:
+        out["run_poismf_abi"] = {"first_iter_ms": _r(abi.get("abi_ms_first_iter")), "per_extra_iter_ms": _r(abi.get("abi_ms_per_extra_iter")),
+                                 "first_iter_ms_cache_on": _r(abi.get("abi_ms_first_iter_cache_on"))}
+    out["full"] = "bench_full.json"
+    return out
+
+
+def write_full(full):
+    """the whole object (launch lists, notes, per-block rooflines, CPU legs) next to bench.py and, on a gpurun box, under gpurun_out/"""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    json.dump(full, f)
+            except OSError:
+                pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -569,8 +634,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        write_full(final_line)
         sys.stdout.flush()
-        print(json.dumps(final_line), flush=True)  # the one JSON line, after RCCL has printed whatever it prints
+        # the one JSON line, LAST on stdout, after RCCL has printed whatever it prints: compact (see compact_line)
+        print(json.dumps(compact_line(final_line), separators=(",", ":")), flush=True)
 
 
 if __name__ == "__main__":
