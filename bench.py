@@ -271,15 +271,26 @@ def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
     l2, mu, _ = harness.auto_defaults(method, K)
     maxupd = mu if maxupd is None else maxupd
     A0, B0 = harness.initialize_matrices(dimA, dimB, K, use_float, 1)
-    t = {1: [], 6: []}
-    for numiter in (1, 1, 6, 1, 6, 1, 6):   # (the first call also pays device initialisation: dropped)
-        A, B = A0.copy(), B0.copy()
-        t0 = time.perf_counter()
-        with np.errstate(all="ignore"):
-            api._run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], A, B, method, True, l2, 0., 1., 1e-7, numiter, maxupd,
-                            False, True, True, 1)
-        t[numiter].append((time.perf_counter() - t0) * 1e3)
+    def calls(seq):
+        t = {1: [], 6: []}
+        for numiter in seq:
+            A, B = A0.copy(), B0.copy()
+            t0 = time.perf_counter()
+            with np.errstate(all="ignore"):
+                api._run_poismf(csr[0], csr[1], csr[2], csc[0], csc[1], csc[2], A, B, method, True, l2, 0., 1., 1e-7, numiter, maxupd,
+                                False, True, True, 1)
+            t[numiter].append((time.perf_counter() - t0) * 1e3)
+        return t
+
+    # the library's default: nothing survives a call (every device array is freed before run_poismf returns, as the reference does)
+    api.set_device_cache_mb(0, use_float)
+    t = calls((1, 1, 6, 1, 6, 1, 6))   # (the first call also pays the pinned staging chunks: dropped)
     t1, t6 = min(t[1][1:]), min(t[6])
+    # opted in to keeping released device arrays between calls (POISMF_HIP_DEVICE_CACHE_MB / poismf_hip_set_device_cache_mb)
+    api.set_device_cache_mb(16384, use_float)
+    tc = calls((1, 1, 1, 1))
+    t1_cache = min(tc[1][1:])
+    api.set_device_cache_mb(0, use_float)
     # where a call's time goes: the same steps through the session entry points, each timed (min of 3): what run_poismf does inside
     split = {"session_create_upload_X_and_sort": [], "factors_up": [], "one_iteration": [], "factors_down": [], "destroy": []}
     outA, outB = A0.copy(), B0.copy()   # (touched pages, as run_poismf's own in / out arrays are)
@@ -300,14 +311,14 @@ def abi_timing(csr, csc, dimA, dimB, method, use_float, maxupd):
         te = time.perf_counter()
         for name, dt in zip(split, (ta - t0, tb - ta, tc - tb, td - tc, te - td)):
             split[name].append(dt * 1e3)
-    return {"abi_ms_first_iter": t1, "abi_ms_per_extra_iter": (t6 - t1) / 5.0, "abi_ms_six_iters": t6,
+    return {"abi_ms_first_iter": t1, "abi_ms_first_iter_cache_on": t1_cache, "abi_ms_per_extra_iter": (t6 - t1) / 5.0, "abi_ms_six_iters": t6,
             "samples_ms": {"numiter1": t[1][1:], "numiter6": t[6]}, "first_call_ms": t[1][0],
             "split_ms": {k_: min(v) for k_, v in split.items()},
             "note": f"run_poismf(method={method}, maxupd={maxupd}, {'fp32' if use_float else 'fp64'}) on the workload matrix through "
                     "ctypes: min of 3 calls each with numiter 1 and 6; per_extra_iter = (min t6 - min t1) / 5.  The process's first run_poismf "
-                    "call (first_call_ms; the device is up by then, the blocks above ran first) also pays the pinned staging chunks and its hipMallocs; "
-                    "later calls find their device arrays in the library's list of released ones (devmem.hpp, "
-                    "POISMF_HIP_DEVICE_CACHE_MB) and their streams recycled"}
+                    "call (first_call_ms; the device is up by then, the blocks above ran first) also pays the pinned staging chunks.  abi_ms_first_iter "
+                    "is the library's default (every device array freed before the call returns); abi_ms_first_iter_cache_on is the same call "
+                    "after poismf_hip_set_device_cache_mb(16384): released arrays are kept for the next call (devmem.hpp)"}
 
 
 _CPU_CACHE = {}

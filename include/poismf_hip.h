@@ -278,11 +278,14 @@ POISMF_HIP_API int poismf_hip_factors_multiple_decisions(real_t *A, real_t *B, r
                           real_t step_size, size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean,
                           unsigned *decisions);
 
-/* Device arrays of 1 MB and more that a finished session (or run_poismf call) releases are kept, up to POISMF_HIP_DEVICE_CACHE_MB
- * (default 16384, 0 = never) per process, for the next request of the same size on the same device -- repeated fits on one shape
- * of matrix then allocate nothing.  This hands them back to the driver.  (The reference frees its scratch at the end of
- * run_poismf, ref src/poismf.c:610-619; so does this library, into its own list.) */
+/* Nothing survives run_poismf by default: every device array the call allocated is freed before it returns, as the reference frees
+ * its scratch (ref src/poismf.c:610-619).  A caller that fits repeatedly on matrices of one shape can OPT IN to keeping released
+ * device arrays of 1 MB and more for the next request of the same size on the same device (repeated fits then allocate nothing and
+ * their uploads run over two DMA queues at full rate): environment POISMF_HIP_DEVICE_CACHE_MB=<MB> or
+ * poismf_hip_set_device_cache_mb(MB) at run time (returns the previous limit; lowering it frees what no longer fits; the limit is
+ * per loaded flavour of the library).  poismf_hip_release_cache() hands whatever is kept back to the driver. */
 POISMF_HIP_API void poismf_hip_release_cache(void);
+POISMF_HIP_API size_t poismf_hip_set_device_cache_mb(size_t mb);
 
 /* Testing aid (G1): the device's own objective / gradient wrappers at `point`, for every row of a CSR, through whichever row engine a CG
  * half-sweep would use for a row of that length.  which = 0: calc_fun_single + calc_grad_single[_w] (ref src/poismf.c:194-240);

@@ -46,6 +46,7 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
     "poismf_hip_session_launch_profile", "poismf_hip_session_decisions", "poismf_hip_session_decision_stats", "poismf_hip_factors_multiple_decisions",
     "poismf_hip_session_predict", "poismf_hip_session_topn", "poismf_hip_debug_row_eval", "poismf_hip_release_cache",
+    "poismf_hip_set_device_cache_mb",
 )
 
 
@@ -74,6 +75,8 @@ def load_library(use_float):
     lib.poismf_hip_session_decision_stats.restype = i
     lib.poismf_hip_release_cache.argtypes = []
     lib.poismf_hip_release_cache.restype = None
+    lib.poismf_hip_set_device_cache_mb.argtypes = [sz]
+    lib.poismf_hip_set_device_cache_mb.restype = sz
     lib.predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
     lib.predict_multiple.restype = None
     lib.topN.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz, i]
@@ -128,6 +131,22 @@ def load_library(use_float):
     lib.real_t = r
     _LIBS[key] = lib
     return lib
+
+
+def release_cache(use_float=None):
+    """Hand the device arrays the library keeps from finished calls (only when the caller opted in, see set_device_cache_mb) back
+    to the driver.  use_float = None: every flavour loaded in this process (each shared library keeps its own list)."""
+    for key, lib in list(_LIBS.items()):
+        if use_float is None or key == ("r" if use_float == "r" else bool(use_float)):
+            lib.poismf_hip_release_cache()
+
+
+def set_device_cache_mb(mb, use_float=None):
+    """Opt in (mb > 0) to / out (0, the default) of keeping released device arrays for the next call: the reference frees everything
+    before run_poismf returns (ref src/poismf.c:610-619) and so does this library unless told otherwise here or through
+    POISMF_HIP_DEVICE_CACHE_MB.  Returns {flavour: previous limit in MB}.  use_float = None: both Python flavours (loaded if need be)."""
+    keys = (False, True) if use_float is None else (("r" if use_float == "r" else bool(use_float)),)
+    return {k_: int(load_library(k_).poismf_hip_set_device_cache_mb(int(mb))) for k_ in keys}
 
 
 def _ptr(a):

@@ -29,7 +29,7 @@ UNITS = {
     "poismf_hip_pg": (_ROW, ["-DPMF_TU=3"]),
     "poismf_hip_eval": (_ROW, ["-DPMF_TU=4"]),   # evaluation-only kernels behind poismf_hip_debug_row_eval (testing aid)
     "coo_convert": (["coo_convert.hip", "devmem.hpp"], []),
-    "serve": (["serve.hip"], []),
+    "serve": (["serve.hip", "devmem.hpp"], []),
 }
 
 

@@ -196,10 +196,10 @@ int poismf_hip_coo_to_csr_csc(const sparse_ix* row, const sparse_ix* col, const 
     std::vector<unsigned long long> hptr(std::max(dimA, dimB) + 1);
     int rc = 1;
     do {
-        if (hipMalloc(&d_row, sizeof(unsigned) * n) != hipSuccess || hipMalloc(&d_col, sizeof(unsigned) * n) != hipSuccess ||
-            hipMalloc(&d_minor, sizeof(unsigned) * n) != hipSuccess || hipMalloc(&d_val, sizeof(real_t) * n) != hipSuccess ||
-            hipMalloc(&d_oval, sizeof(real_t) * n) != hipSuccess ||
-            hipMalloc(&d_ptr, sizeof(unsigned long long) * (std::max(dimA, dimB) + 1)) != hipSuccess)
+        if (pmf_malloc_retry((void**)&d_row, sizeof(unsigned) * n) != hipSuccess || pmf_malloc_retry((void**)&d_col, sizeof(unsigned) * n) != hipSuccess ||
+            pmf_malloc_retry((void**)&d_minor, sizeof(unsigned) * n) != hipSuccess || pmf_malloc_retry((void**)&d_val, sizeof(real_t) * n) != hipSuccess ||
+            pmf_malloc_retry((void**)&d_oval, sizeof(real_t) * n) != hipSuccess ||
+            pmf_malloc_retry((void**)&d_ptr, sizeof(unsigned long long) * (std::max(dimA, dimB) + 1)) != hipSuccess)
             break;
         for (size_t i = 0; i < n; i++) h32[i] = (unsigned)row[i];
         if (hipMemcpy(d_row, h32.data(), sizeof(unsigned) * n, hipMemcpyHostToDevice) != hipSuccess) break;

@@ -14,6 +14,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,9 +54,12 @@ inline bool pmf_async_alloc()
 // queue, while arrays of that size are being allocated and freed around them).  So blocks of 1 MB and more go to a per-process list
 // when they are released and come back to the next request of exactly their size on their device: repeated fits on matrices of one
 // shape -- a hyper-parameter search, the bench's run_poismf leg -- find all their arrays there.  The list holds at most
-// POISMF_HIP_DEVICE_CACHE_MB (default 16384; 0 = off: plain hipMalloc / hipFree as before), oldest blocks leave first;
-// poismf_hip_release_cache() empties it; an allocation that fails empties it and tries again.  Blocks come back with their old
-// contents (as hipMalloc's are unspecified): nothing here may rely on fresh memory reading as zero.
+// POISMF_HIP_DEVICE_CACHE_MB / poismf_hip_set_device_cache_mb(); oldest blocks leave first; poismf_hip_release_cache() empties it;
+// an allocation that fails empties it and tries again.  Blocks come back with their old contents (as hipMalloc's are unspecified):
+// nothing here may rely on fresh memory reading as zero.
+// OFF BY DEFAULT since round 5 (limit 0: plain hipMalloc / hipFree): the reference frees everything before run_poismf returns (ref:
+// src/poismf.c:610-617, SURVEY 8b "no handles/state survive the call") and so does this library unless the caller opts in -- round 4
+// kept up to 16 GB per process (per flavour library) alive behind the caller's back.  The limit can be changed at run time.
 struct PmfDevCache {
     struct Block { void* p; size_t bytes; int device; };
     std::mutex mu;
@@ -62,20 +67,24 @@ struct PmfDevCache {
     std::unordered_map<void*, std::pair<size_t, int>> live;         // handed out, eligible to come back
     size_t idle_bytes = 0;
     static constexpr size_t LEAST = (size_t)1 << 20;
-    static size_t limit()
+    static std::atomic<size_t>& limit_word()
     {
-        static const size_t v = [] {
+        static std::atomic<size_t> v{ [] {
             const char* e = getenv("POISMF_HIP_DEVICE_CACHE_MB");
-            return (size_t)(e ? atoll(e) : 16384) << 20;
-        }();
+            return (size_t)(e ? atoll(e) : 0) << 20;
+        }() };
         return v;
     }
-    // (mu held)
-    void drop_oldest_until(size_t room)
+    static size_t limit() { return limit_word().load(std::memory_order_relaxed); }
+    // (mu held) takes the oldest blocks off the list until at most `room` bytes are left; the caller hands them to hipFree AFTER
+    // it has released the mutex (hipFree waits for the device: other threads' allocations must not queue behind it)
+    std::vector<void*> take_oldest_until(size_t room)
     {
+        std::vector<void*> out;
         size_t n = 0;
-        while (n < idle.size() && idle_bytes > room) { (void)hipFree(idle[n].p); idle_bytes -= idle[n].bytes; n++; }
+        while (n < idle.size() && idle_bytes > room) { out.push_back(idle[n].p); idle_bytes -= idle[n].bytes; n++; }
         idle.erase(idle.begin(), idle.begin() + (long)n);
+        return out;
     }
 };
 inline PmfDevCache& pmf_dev_cache()
@@ -86,8 +95,37 @@ inline PmfDevCache& pmf_dev_cache()
 inline void pmf_release_cache()
 {
     PmfDevCache& c = pmf_dev_cache();
-    std::lock_guard<std::mutex> lk(c.mu);
-    c.drop_oldest_until(0);
+    std::vector<void*> gone;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        gone = c.take_oldest_until(0);
+    }
+    for (void* p : gone) (void)hipFree(p);
+}
+// new limit in MB (0 = keep nothing: what is on the list now is freed); returns the old one
+inline size_t pmf_set_cache_limit_mb(size_t mb)
+{
+    const size_t old = PmfDevCache::limit_word().exchange(mb << 20, std::memory_order_relaxed) >> 20;
+    PmfDevCache& c = pmf_dev_cache();
+    std::vector<void*> gone;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        gone = c.take_oldest_until(mb << 20);
+    }
+    for (void* p : gone) (void)hipFree(p);
+    return old;
+}
+// hipMalloc for the places that do not go through pmf_alloc (temporaries of the COO conversion, the serving calls): an out-of-memory
+// answer gives the kept blocks back to the driver and asks once more
+inline hipError_t pmf_malloc_retry(void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        pmf_release_cache();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
 }
 
 template <class T> inline hipError_t pmf_alloc(T** p, size_t bytes, hipStream_t stream)
@@ -151,9 +189,17 @@ inline void pmf_free(void* p, hipStream_t stream)
                 (void)hipDeviceSynchronize();
                 if (cur != device && cur >= 0) (void)hipSetDevice(cur);
                 lk.lock();
-                c.drop_oldest_until(PmfDevCache::limit() - bytes);
-                c.idle.push_back({ p, bytes, device });
-                c.idle_bytes += bytes;
+                const size_t lim = PmfDevCache::limit();   // (may have been lowered meanwhile)
+                if (bytes <= lim) {
+                    std::vector<void*> gone = c.take_oldest_until(lim - bytes);
+                    c.idle.push_back({ p, bytes, device });
+                    c.idle_bytes += bytes;
+                    lk.unlock();
+                    for (void* q : gone) (void)hipFree(q);
+                    return;
+                }
+                lk.unlock();
+                (void)hipFree(p);
                 return;
             }
         }

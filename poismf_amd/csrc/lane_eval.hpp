@@ -119,11 +119,17 @@ __device__ __forceinline__ unsigned acc_get(unsigned a)
 // LP_: a further, PARTIAL set of LP_ (16) nonzeros per wave in LDS (lanes >= LP_ of that set alias lanes < LP_ with a zero
 // coefficient), and the transposing reduction's scratch used in two halves -- what makes rows of 1025 .. 1088 nonzeros fit ONE
 // CU: 4 waves x (64 + 128 + 64 + 16) nonzeros, 155 KB of LDS.
-// NH_: row streams ("halves") per workgroup.  NH_ = 2: a workgroup of 2 NW_ waves works on TWO rows that are never in the same
-// phase -- while one half's NW_ waves run the solver's passes over their register tile, the other half's waves have their next
-// row's tile in flight and wait at the same barriers (sweep_rows_paired in poismf_hip.hip): the gather of one row always runs
-// under the solve of another, whatever the dispatcher and the row lengths do.  Each half has its own LDS block.
-template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0, int NH_ = 1> struct LaneEval {
+// TX_ (round 5; doubles, one register set, one wave per row: k = 100 rows of at most 64 nonzeros, config C5's user rows and short item rows):
+// the gradient sum_j c_j F_j is NOT formed by the transposing reduction (for 100 dimensions: 78 double swap folds at ~32 cycles each,
+// 100 partial products and, because hipcc keeps the 200-register tile of these instances in AGPRs, 200 v_accvgpr_reads at 6 cycles --
+// 5.2 k of an evaluation's 10 k cycles, scripts/probes/f64_probe.hip and the duplication builds of DESIGN.md 6.0b) but the way the
+// reference forms it (ref: src/poismf.c:126-133, :262-267: one daxpy per nonzero, in order): the tile sits in LDS as the row-major
+// image [nonzero][slots] (written once per row), every lane owns its two dimensions, and per nonzero j it takes c_j as a scalar (two
+// v_readlane) and its two elements of row j (conflict-free ds_read_b64) into two multiply-adds -- six instructions per nonzero,
+// nothing per dimension, the reference's own summation order.  The dots read the same image (lane j its own row, one ds_read_b128
+// per slot, row stride 816 bytes = conflict-free), so NO tile lives in registers: the solver's state has the 256 architectural
+// registers to itself and the v_accvgpr traffic is gone.  TX_ = rows of the image: 48 (39 KB: four rows per CU) or 64 (52 KB: three).
+template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0, int TX_ = 0> struct LaneEval {
     using SA = typename Slot<T>::A;
     static constexpr int SN = Slot<T>::N;                 // elements per 16-byte slot
     static constexpr int KP = KS * SN;                    // elements of a factor row, padded to whole slots
@@ -131,7 +137,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr int LP = LP_;                                                  // nonzeros of the partial LDS set (0: none)
     static constexpr int LLT = LL_ + (LP_ > 0 ? 1 : 0);                              // sets read from LDS (the partial one last)
     static constexpr int LV = LV_, LA = LA_, LL = LL_, LR = LV_ + LA_, LT = LV_ + LA_ + LLT;   // sets: VGPR, AGPR, LDS
-    static_assert(LP_ == 0 || (LL_ > 0 && (LP_ & (LP_ - 1)) == 0 && LP_ < WAVE), "a partial set comes after a full LDS set");
+    static_assert(LP_ == 0 || ((LP_ & (LP_ - 1)) == 0 && LP_ < WAVE), "a partial set: a power of two of nonzeros, the last set of the wave");
     static constexpr int L = LT, NW = NW_, M = 1;
     static constexpr int W = KS < 13 ? KS : 13;           // slots per staged chunk (row stride of the LDS image: 13 slots = 52 banks, conflict-free b128 reads)
     static constexpr int NCH = (KS + W - 1) / W;          // chunks per factor row; chunk c starts at slot min(c W, KS - W)
@@ -190,18 +196,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #ifndef PMF_LANE_COAL
 #define PMF_LANE_COAL 1
 #endif
-#ifndef PMF_LANE_PF_LDS
-#define PMF_LANE_PF_LDS 0   // measured and NOT adopted (scripts/probes/time_bhalf.py, C4 matrix, the 78.7 k item rows of 513 .. 1024 nonzeros):
-                            // 4.41 ms with it, 4.26 without at ten passes (3.20 against 3.25 at six) -- see PF_LDS below
-#endif
 #ifdef PMF_ABLATE_DOTS
 #define PMF_ABLATE_DOTS_ON 1
 #else
 #define PMF_ABLATE_DOTS_ON 0
-#endif
-#ifndef PMF_LANE_BANKED
-#define PMF_LANE_BANKED 0   // 1: the butterfly's two upper levels as bank-masked DPP adds on full batches of sixteen (43 fewer instructions per pass, 16 more
-                            // live registers: the headline instance then spills 16-24 bytes per lane; measured on the C4 matrix: 4.25 ms either way)
 #endif
     // COAL (round 4; with XPOSE): the register sets are fetched by COALESCED loads -- instruction i of a set reads the 64 consecutive
     // 16-byte slots 64 i .. 64 i + 63 of the row-major image [nonzero][W slots], i.e. W adjacent lanes share a factor row, as the
@@ -212,16 +210,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // of round 4 put the gather of a 1000-nonzero fp32 row at 26 k of its 62 k cycles.
     static constexpr bool COAL = PMF_LANE_COAL && XPOSE && LA_ == 0 && PMF_LANE_DIRECT;
     static_assert(!COAL || (STAGE_BYTES <= KS * XP_QS * 16 && KS == W), "a whole set's image fits the reduction's image");
-    // PF_LDS (round 4; with COAL and the butterfly reduction, which leaves the LDS image idle during a solve): while a row is being
-    // solved, the FIRST SET of the next row's tile is fetched into that image by LDS-DMA (prefetch_tile(), called by pg_row after its
-    // first pass: the next row's indices have landed by then and no register is needed); the row switch then reads that set out of LDS
-    // and fetches only the other sets from memory.  The ablation runs of round 4 (scripts/probes/time_bhalf.py) put this launch at
-    // gather floor + the part of ten passes that does not hide under the OTHER workgroup's gather: a quarter of every gather moved
-    // under the row's own passes.  The registers hold one tile and no more; LDS holds 13 KB per wave: one set of four.
-    // Result: slower.  The thirteen DMA instructions and their address arithmetic are issued by the wave that is computing (a
-    // hundred-odd instructions per row on a SIMD that is the bottleneck while both workgroups of a CU compute), and what they save is a
-    // quarter of a gather that the other workgroup's passes were already covering most of the time.
-    static constexpr bool PF_LDS = PMF_LANE_PF_LDS && COAL && PMF_LANE_XPOSE == 2;
 #ifndef PMF_LANE_FIVE
 #define PMF_LANE_FIVE 0   // doubles, one VGPR set + one LDS set, one wave per row: the scratch in two halves brings a wave's LDS from 36.3 to 31.1 KB,
                           // i.e. FIVE rows per CU instead of four, one SIMD taking two waves.  Measured, C3 A half: 19.8 -> 23.9 ms (maxupd 1:
@@ -231,17 +219,23 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr bool FIVE = PMF_LANE_FIVE && sizeof(T) == 8 && LV_ == 1 && LA_ == 0 && LL_ == 1 && NW_ == 1 && !PF_ && LP_ == 0;
     static constexpr int RED_PH = (LP_ > 0 || FIVE) ? 2 : 1;        // the columns pass through the scratch in this many groups
     static constexpr int RED_COLS = RED_PH == 1 ? 16 : (CW + 1) / 2;
-    static constexpr int RED_BYTES = XPOSE ? KS * XP_QS * 16 : 4 * RED_COLS * RED_STRIDE; // four 16-lane rows x the columns of a group
+    static constexpr int TX = TX_;
+    static_assert(TX_ == 0 || (LV_ == 1 && LA_ == 0 && LL_ == 0 && LP_ == 0 && NW_ == 1 && !PF_ && !SMALL_ && sizeof(T) == 8 && TX_ % 4 == 0 && TX_ <= WAVE),
+                  "the LDS image of the tile: doubles, one register set, one wave per row");
+    // (row-major [TX][KS + 1 slots]: the gradient reads ALONG a row -- conflict-free whatever the stride --, the dots and the image's writes
+    // go DOWN a column, lane = row: a stride of 51 slots = 204 banks puts the 16 lanes of a ds_read_b128 service group on 16 different
+    // bank quads.  53 040 bytes per wave at TX = 64: three rows per CU -- the 13-slot chunk images of the staging buffers, 54 064 bytes, made it two)
+    static constexpr int TX_STRIDE = (KS + 1) * 16;
+    static constexpr int TX_BYTES = TX_ > 0 ? TX_ * TX_STRIDE : 0;
+    static constexpr int RED_BYTES = TX_ > 0 ? 0 : (XPOSE ? KS * XP_QS * 16 : 4 * RED_COLS * RED_STRIDE); // four 16-lane rows x the columns of a group
     // one chunk of the partial set: LP_ rows of W slots, rounded up to whole DMA instructions (64 lanes x 16 bytes) so that no
     // lane has to be masked off -- the lanes past the image fetch some row's slots into the padding
     static constexpr int PART_BYTES = LP_ > 0 ? (LP_ * W * 16 + 1023) / 1024 * 1024 : 0;
     static constexpr int AVEC_BYTES = (KP * (int)sizeof(T) + 15) / 16 * 16;
-    static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES) + AVEC_BYTES;
+    static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES) + TX_BYTES + AVEC_BYTES;
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
     static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) : 0;
-    static constexpr int NH = NH_;
-    static constexpr int HALF_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;   // one row stream's LDS block
-    static constexpr int SMEM_BYTES = NH * HALF_BYTES;
+    static constexpr int SMEM_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;
 #ifndef PMF_LANE_SPOINT
 #define PMF_LANE_SPOINT 1   // floats, all sets in registers: the point reaches the dots as SCALAR operands (set_point keeps it in a register,
                             // lane <-> dimension; eval() takes dimension c with one v_readlane and multiplies by the SGPR) instead of an LDS
@@ -287,8 +281,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     unsigned zero_row;
     int k, ldF;
     int lane, wid;
-    int half;            // NH_ > 1: which of the workgroup's row streams this wave belongs to
-    unsigned nbar;       // NH_ > 1: workgroup barriers this wave has passed since the row stream's driver last reset the count
     static constexpr int member = 0;
     struct ElemOf {   // factor dimension held in element i of this lane (only meaningful where act[i])
         int d0;
@@ -296,14 +288,14 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     } elem;
     bool act[NC];
     bool holds_dim;      // this lane holds a dimension of the padded k-vector (elem.d0 < DB)
-    bool meta_fresh;     // PF_LDS: idx_n holds the indices of a row whose tile has not been requested yet (fetch_meta -> prefetch_tile / gather)
-    bool pf_have;        // PF_LDS: the image holds (or is receiving) set 0 of the row idx_n names
     unsigned nnz;        // nonzeros of the row held by THIS wave
     unsigned n_eval;
     unsigned char* stage;   // this wave's NBUF staging buffers
     unsigned char* part;    // this wave's partial LDS set (LP_ > 0): NCH chunk images of LP_ rows
     unsigned char* red;     // this wave's transpose scratch
     SA* avec;               // this wave's copy of the current point, as slots
+    unsigned char* tximg;   // TX_ > 0: this wave's LDS image of the tile
+    unsigned txoff[NC];     // TX_ > 0: byte offset of this lane's dimension i inside a row of the image (chunk base included)
     unsigned char* xw_base; // NW > 1: cross-wave scratch
     int xw_sel;
     unsigned* ticket_word;
@@ -317,16 +309,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     __device__ __forceinline__ void init(const TileGeom& geo, const T* F_, unsigned char* smem)
     {
         lane = lane_id();
-        if constexpr (NH > 1) {   // (wave-uniform, and said so: the row stream's bookkeeping then lives in scalar registers)
-            const int wave = uniform((int)(threadIdx.x / WAVE));
-            wid = wave % NW;
-            half = wave / NW;
-        } else {
-            wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
-            half = 0;
-        }
-        nbar = 0;
-        smem += (size_t)half * HALF_BYTES;
+        wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
         const int col = lane & 15, rr = lane >> 4;
         elem.d0 = XPOSE ? lane : col + CW * rr;
         const bool lane_on = XPOSE ? lane < DB : (col < CW && elem.d0 < DB);
@@ -337,14 +320,21 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         stage = p;
         part = p + NBUF * STAGE_BYTES;
         red = ALIAS ? p : p + NBUF * STAGE_BYTES + NCH * PART_BYTES;
-        avec = (SA*)(p + NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES));
+        tximg = p + NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES);
+        avec = (SA*)(p + NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES) + TX_BYTES);
+        if constexpr (TX > 0) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                const int d = lane_on ? elem[i] : 0;
+                txoff[i] = (unsigned)(d * (int)sizeof(T));
+            }
+        }
         xw_base = smem + (size_t)NW * WAVE_BYTES;
         xw_sel = 0;
         ticket_word = (unsigned*)(smem + (size_t)NW * WAVE_BYTES + 2 * XW_BYTES);
 #pragma unroll
         for (int i = 0; i < NC; i++) act[i] = lane_on && elem[i] < k;
         pq_cap = 0x7fffffff;
-        meta_fresh = false; pf_have = false;
         pbuf = (T*)(size_t)16; qbuf = (T*)(size_t)32;   // tags, never dereferenced
         n_eval = 0;
         nnz = 0;
@@ -511,34 +501,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             const unsigned j = (unsigned)(WAVE * s + lane);
             idx_n[s] = j < mine ? ind[c0 + j] : zero_row;   // lanes past the end of the row fetch the all-zero row behind F
         }
-        if constexpr (PF_LDS) meta_fresh = true;
-    }
-    // PF_LDS: set 0 of the row whose indices fetch_meta fetched last -> the LDS image, as W LDS-DMA instructions (the row-major image
-    // [nonzero][W slots] the coalesced gather builds through registers).  Called from inside the solve of the CURRENT row.
-    __device__ __forceinline__ void prefetch_tile()
-    {
-        if constexpr (PF_LDS) {
-            if (!meta_fresh) return;
-            meta_fresh = false;
-            pf_have = true;
-            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
-            unsigned lane_here = (unsigned)lane;
-            asm volatile("" : "+v"(lane_here));
-            unsigned j4 = (lane_here / (unsigned)W) * 4u;
-            unsigned q16 = (lane_here % (unsigned)W) * 16u;
-            static_for<0, W>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                const unsigned c = (unsigned)__builtin_amdgcn_ds_bpermute((int)j4, (int)idx_n[0]);
-                const unsigned off = __umul24(c, rowbytes) + q16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)F + (size_t)off),
-                                                 (__attribute__((address_space(3))) void*)(red + i * 1024), 16, 0, 0);
-                j4 += (unsigned)(WAVE / W) * 4u;
-                q16 += (unsigned)(WAVE % W) * 16u;
-                const bool wrap = q16 >= (unsigned)(W * 16);
-                q16 = wrap ? q16 - (unsigned)(W * 16) : q16;
-                j4 = wrap ? j4 + 4u : j4;
-            });
-        }
     }
     __device__ __forceinline__ void begin_row(const unsigned* ind, const T* val, unsigned nnz_row)
     {
@@ -634,9 +596,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             // solver, i.e. in scratch)
             unsigned lane_here = (unsigned)lane;
             asm volatile("" : "+v"(lane_here));
-            // (PF_LDS: set 0 is in the image already, or on its way there)
-            const bool have0 = PF_LDS && pf_have;
-            if constexpr (PF_LDS) { pf_have = false; meta_fresh = false; }
             auto request_set = [&](auto sc) {
                 constexpr int s2 = decltype(sc)::value;
                 unsigned j4 = (lane_here / (unsigned)W) * 4u;            // byte address of the row's index for ds_bpermute
@@ -680,17 +639,30 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 wave_lds_fence();
                 own_rows_of_image(sc);
             };
-            if (have0) {
-                // the other sets' loads go out first; then the prefetched set leaves the image, which is the staging buffer after that
-                static_for<1, LV>(request_set);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LV - 1) * W < 63 ? (LV - 1) * W : 63) : "memory");   // (the DMA is older than those loads)
-                wave_lds_fence();
-                own_rows_of_image(std::integral_constant<int, 0>{});
-                static_for<1, LV>(through_image);
-            } else {
-                static_for<0, LV>(request_set);
-                static_for<0, LV>(through_image);
+            static_for<0, LV>(request_set);
+            static_for<0, LV>(through_image);
+        } else if constexpr (TX > 0) {
+            // TX: this lane's factor row, 16 bytes at a time, into free registers (the solver's state is dead between two rows) and
+            // from there into the row-major image in LDS (lanes past the row's end fetch the zero row)
+            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
+            const char* base = (const char*)F + (size_t)__umul24(idx[0], rowbytes);
+            typename Slot<T>::U tmp[KS];
+            static_for<0, KS>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                tmp[q] = *(const typename Slot<T>::U*)(base + q * 16);
+            });
+            wave_lds_fence();   // (the previous row's last reads of the image are older than these writes)
+            if (TX == WAVE || lane < TX) {
+                SA* row = (SA*)(tximg + lane * TX_STRIDE);
+                static_for<0, KS>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    SA v;
+#pragma unroll
+                    for (int e = 0; e < SN; e++) v.v[e] = tmp[q].v[e];
+                    row[q] = v;
+                });
             }
+            wave_lds_fence();
         } else if constexpr (DIRECT_V) {
             const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
             static_for<0, LV>([&](auto sc) {
@@ -763,8 +735,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         if constexpr (DIRECT_A && LA > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (ALIAS) { __builtin_amdgcn_s_waitcnt(0xc07f); wave_lds_fence(); }   // the scratch of the reductions is this buffer
         // LDS sets: their chunks stay in the buffers (set u, chunk c in buffer u NCH + c)
-        if constexpr (LL > 0) {
-            if constexpr (!TEMP_A) request_lds_sets();
+        if constexpr (LL > 0 || LP > 0) {
+            if constexpr (!(TEMP_A && LL > 0)) request_lds_sets();
             wait_dma<0>();
         }
     }
@@ -920,21 +892,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 constexpr int N = KP - 16 * b < 16 ? KP - 16 * b : 16;        // partials of this batch
                 T q[8], r[4], s2[2];
                 constexpr int N8 = N < 8 ? N : 8;
-                if constexpr (N == 16 && PMF_LANE_BANKED) {
-                    // a full batch: all sixteen lane-partials (sixteen independent multiply-add chains, SET-major), then the two upper
-                    // levels as bank-masked DPP adds -- two instructions per fold instead of two selects and an add (reg_eval.hpp)
-                    T u[16];
-                    static_for<0, LV>([&](auto sc) {
-                        constexpr int s_ = decltype(sc)::value;
-                        static_for<0, 16>([&](auto jc) {
-                            constexpr int j = decltype(jc)::value;
-                            if constexpr (s_ == 0) u[j] = coef[0] * t[0][16 * b + j];
-                            else u[j] = fma_t(coef[s_], t[s_][16 * b + j], u[j]);
-                        });
-                    });
-                    fold16_banked(u, q);
-                    fold8_banked(q, r);
-                } else {
+                {
                     // the lane-partials of eight dimensions at a time, SET-major: eight independent multiply-add chains side by side
                     // (column by column the chains were two wide: a dependent v_fmac every other instruction)
                     static_for<0, 2>([&](auto hc) {
@@ -1048,6 +1006,46 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         return result;                                  // lane (R, c): dimension c + CW R (lanes with c >= CW: nothing)
     }
 
+    // TX: tot_i = sum_j coef_j T[j][dimension i of this lane], j in the row's own order (ONES: every coefficient 1).  Four nonzeros per
+    // block, the next block's eight elements requested before this block's multiply-adds; blocks past the row's end are skipped (wave-uniform).
+    template <bool ONES> __device__ __forceinline__ void tx_axpy(T coef, T (&tot)[NC]) const
+    {
+        constexpr int JB = 4, NB = TX / JB;
+        T acc[NC];
+#pragma unroll
+        for (int i = 0; i < NC; i++) acc[i] = (T)0;
+        T buf[2][JB][NC];
+        auto load = [&](auto bc, T (&b_)[JB][NC]) {
+            constexpr int j0 = decltype(bc)::value * JB;
+#pragma unroll
+            for (int u = 0; u < JB; u++) {
+#pragma unroll
+                for (int i = 0; i < NC; i++) b_[u][i] = *(const T*)(tximg + txoff[i] + (j0 + u) * TX_STRIDE);
+            }
+        };
+        const unsigned n_here = uniform(nnz);   // (wave-uniform, and said so: the blocks below are scalar branches)
+        load(std::integral_constant<int, 0>{}, buf[0]);
+        static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            if (n_here > (unsigned)(JB * b)) {
+                if constexpr (b + 1 < NB) load(std::integral_constant<int, b + 1>{}, buf[(b + 1) & 1]);
+#pragma unroll
+                for (int u = 0; u < JB; u++) {
+                    if constexpr (ONES) {
+#pragma unroll
+                        for (int i = 0; i < NC; i++) acc[i] += buf[b & 1][u][i];
+                    } else {
+                        const T c = read_lane(coef, JB * b + u);
+#pragma unroll
+                        for (int i = 0; i < NC; i++) acc[i] = fma_t(c, buf[b & 1][u][i], acc[i]);
+                    }
+                }
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < NC; i++) tot[i] = act[i] ? acc[i] : (T)0;
+    }
+
     // NW > 1: add up the NW waves' results (fixed order; every wave ends with the same bits)
     __device__ __forceinline__ void combine_waves(T (&tot)[NC], double& lsum, bool vec = true)
     {
@@ -1061,7 +1059,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             }
             if (lane == 0) xl[wid] = lsum;
             __syncthreads();
-            if constexpr (NH > 1) nbar++;
             double lp[NW];
 #pragma unroll
             for (int w = 0; w < NW; w++) lp[w] = xl[w];
@@ -1122,7 +1119,44 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                     }
                 });
             });
+        } else if constexpr (TX > 0) {
+            // TX: lane j's own row of the LDS image against the point (a broadcast read), slots in groups of GQ, the next group requested
+            // before the current group's multiply-adds; the plain left-to-right chain of KP multiply-adds of the other instances
+            auto dots = [&](T (&pred)[LT]) {
+                constexpr int GQ = 5, NG = (KS + GQ - 1) / GQ;
+                const SA* row = (const SA*)(tximg + ((TX == WAVE || lane < TX) ? lane : 0) * TX_STRIDE);   // (lanes past the image: some row's finite data, coefficient 0)
+                SA av[2][GQ], tv[2][GQ];
+                auto load_group = [&](auto gc, SA (&a_)[GQ], SA (&t_)[GQ]) {
+                    constexpr int g = decltype(gc)::value;
+                    static_for<0, GQ>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, q = g * GQ + i;
+                        if constexpr (q < KS) { a_[i] = avec[q]; t_[i] = row[q]; }
+                    });
+                };
+                load_group(std::integral_constant<int, 0>{}, av[0], tv[0]);
+                static_for<0, NG>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, av[(g + 1) & 1], tv[(g + 1) & 1]);
+                    pin_here();
+                    static_for<0, GQ>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, q = g * GQ + i;
+                        if constexpr (q < KS) {
+                            if constexpr (q == 0) pred[0] = tv[g & 1][i].v[0] * av[g & 1][i].v[0];
+                            else pred[0] = fma_t(tv[g & 1][i].v[0], av[g & 1][i].v[0], pred[0]);
+#pragma unroll
+                            for (int e = 1; e < SN; e++) pred[0] = fma_t(tv[g & 1][i].v[e], av[g & 1][i].v[e], pred[0]);
+                        }
+                    });
+                    asm volatile("" : "+v"(pred[0]));
+                    pin_here();
+                });
+            };
+#ifdef PMF_DUP_DOTS
+            { T p2[LT]; dots(p2); asm volatile("" :: "v"(p2[0])); }
+#endif
+            dots(pred);
         } else {
+            auto dots = [&](T (&pred)[LT]) {
             // slots in groups of GQ: the point (a broadcast read) and the LDS sets' slots of the NEXT group are requested
             // before the current group's multiply-adds
             constexpr int GQ = PMF_LANE_GQ(LA_, LP_), NG = (KS + GQ - 1) / GQ;
@@ -1165,6 +1199,11 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 for (int s2 = 0; s2 < LT; s2++) asm volatile("" : "+v"(pred[s2]));
                 pin_here();
             });
+            };
+#ifdef PMF_DUP_DOTS   // development: the dots made twice (same results): the difference to the plain build is what they cost
+            { T p2[LT]; dots(p2); for (int s2 = 0; s2 < LT; s2++) asm volatile("" :: "v"(p2[s2])); }
+#endif
+            dots(pred);
         }
         PMF_STAMP(*this, 1);
         if (store == pbuf) {
@@ -1176,6 +1215,21 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         }
         double lpart = 0.0;
         T coef[LT];
+#ifdef PMF_DUP_COEF   // development: logarithms and divisions made twice
+        {
+            double l2nd = 0.0;
+            T c2[LT];
+#pragma unroll
+            for (int s = 0; s < LT; s++) {
+                T pr2 = pred[s];
+                asm volatile("" : "+v"(pr2));
+                const bool on = (unsigned)(WAVE * s + lane) < nnz;
+                if constexpr (WANT_F) l2nd += on ? (double)xr[s] * d_log((double)pr2) : 0.0;
+                if constexpr (WANT_G) { c2[s] = on ? coef_div(sgn * xr[s], pr2) : (T)0; asm volatile("" :: "v"(c2[s])); }
+            }
+            asm volatile("" :: "v"(l2nd));
+        }
+#endif
 #pragma unroll
         for (int s = 0; s < LT; s++) {
             const bool on = (unsigned)(WAVE * s + lane) < nnz;
@@ -1186,7 +1240,19 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #pragma unroll
         for (int i = 0; i < NC; i++) tot[i] = (T)0;
         PMF_STAMP(*this, 2);
-        if constexpr (WANT_G) {
+        if constexpr (WANT_G && TX > 0) {
+#ifdef PMF_DUP_RED
+            { T t2[NC]; tx_axpy<false>(coef[0], t2); asm volatile("" :: "v"(t2[0])); }
+#endif
+            tx_axpy<false>(coef[0], tot);
+        } else if constexpr (WANT_G) {
+#ifdef PMF_DUP_RED   // development: the transposing reduction (with its partial products) made twice
+            static_for<0, NC>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                T r = reduce_block<b>(coef);
+                asm volatile("" :: "v"(r));
+            });
+#endif
             static_for<0, NC>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
                 const T r = reduce_block<b>(coef);
@@ -1283,7 +1349,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         for (int s = 0; s < LT; s++) one[s] = (T)1;   // lanes past the row's end hold the zero row
         if constexpr (LP > 0) one[LT - 1] = lane < LP ? (T)1 : (T)0;   // (the partial set's lanes >= LP alias rows of its first lanes)
         T tot[NC];
-        static_for<0, NC>([&](auto bc) {
+        if constexpr (TX > 0) tx_axpy<true>((T)1, tot);   // (rows past the end of the row are the zero row)
+        else static_for<0, NC>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
             const T r = reduce_block<b>(one);
             tot[b] = act[b] ? r : (T)0;

@@ -57,6 +57,8 @@ template <class T> struct HalfArgs {
     int reuse_prev, early_stop;
     unsigned* n_unchanged;
     unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
+    const unsigned* stop;             // != nullptr (CG / TNCG launches whose rows are dealt out statically): the word the host overwrites when the call is
+                                      // interrupted -- read before every row, as the reference's row loops read should_stop_procedure (ref: src/poismf.c:301, :360)
     unsigned* eval_rows;              // != nullptr (profiling sessions): [local row] += passes over that row's tile
     unsigned* dec_rows;               // != nullptr (profiling sessions): [2 x local row] = the solver's decisions (solvers.hpp, SolveStats)
     unsigned long long* team_buf;     // team launches (several CUs per row, reg_eval.hpp M_ > 1): arrival counters, mailboxes, exchange slots
@@ -65,8 +67,6 @@ template <class T> struct HalfArgs {
     const unsigned* gate;             // != nullptr: the kernel runs only if *gate != 0 (the streamed re-run of a team launch that gave up)
     unsigned* arrive;                 // != nullptr (the long-row launch on the second stream): every workgroup counts itself in here when it
                                       // starts -- the main stream holds the other bins' kernels back until the long rows are on the chip
-    unsigned stagger;                 // != 0 (PG, several waves per row): a workgroup idles a pseudo-random number of shader cycles below this
-                                      // bound before its first row, so that the chip's CUs are not all gathering (or all computing) at once
 };
 
 enum { K_PG = 3, K_CG = 2, K_TNCG = 1, K_EVAL = 4 };
@@ -183,7 +183,7 @@ inline TeamShape team_shape_for(unsigned max_nnz)
 // shortest rows) and of 13 slots in floats (k = 49..52).  Lane sets (64 nonzeros each) per wave -- in architectural registers,
 // in accumulator registers, in LDS -- and waves per row for rows of a length class; waves 0 = not a row of this engine.
 // A function of the class bound (and the solver) alone, so a row's arithmetic does not depend on its shard.
-struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; int pair = 0; };   // pair: two row streams per workgroup (lane_eval.hpp, NH_ = 2)   // small: a few KB of LDS per wave, two waves per SIMD; lp: nonzeros of a partial LDS set
+struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; int tx = 0; };   // tx: rows of the LDS image the gradient is accumulated from (lane_eval.hpp, TX_)   // small: a few KB of LDS per wave, two waves per SIMD; lp: nonzeros of a partial LDS set
 #ifndef PMF_LANE_A2
 #define PMF_LANE_A2 0   // doubles, rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
                         // (measured, C3 A half, CG fp64: 22.3 ms against 20.0 -- the barrier per evaluation and the second copy of the
@@ -204,11 +204,21 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
             if (cls <= 1024) return { 1, 2, 1, 4, 0 };
             if (cls <= 1088) return { 1, 2, 1, 4, 0, 16 };   // 4 x (64 + 128 + 64 + 16) nonzeros: C3's item rows (Poisson(1000)) end here but for 0.3 %
         } else if (s_load == 50) {   // a set is 200 registers / 51 KB of LDS
+            // rows of at most 64 nonzeros: the gradient from a second, row-major copy of the tile in LDS instead of the transposing
+            // reduction (lane_eval.hpp, TX_): 39 KB of LDS for up to 48 nonzeros (four rows per CU), 52 KB up to 64 (three).
+            // POISMF_HIP_NO_TX=1: the reduction (rounds 3-4)
+            static const bool no_tx = getenv("POISMF_HIP_NO_TX") != nullptr;
+            if (cls <= 48 && !no_tx) return { 1, 0, 0, 1, 0, 0, 48 };
+            if (cls <= 64 && !no_tx) return { 1, 0, 0, 1, 0, 0, 64 };
             if (cls <= 64) return { 1, 0, 0, 1, 0 };
             // (two such rows per CU: config C5's user rows of 65 .. ~95 nonzeros leave the streamed path; tuning knob
             // POISMF_HIP_K100_LANE_MAX=<64|128>)
-            static const unsigned k100_max = getenv("POISMF_HIP_K100_LANE_MAX") ? (unsigned)atoi(getenv("POISMF_HIP_K100_LANE_MAX")) : 128u;
+            static const unsigned k100_max = getenv("POISMF_HIP_K100_LANE_MAX") ? (unsigned)atoi(getenv("POISMF_HIP_K100_LANE_MAX")) : 384u;
             if (cls <= 128 && cls <= k100_max) return { 1, 0, 1, 1, 0 };
+            // 129 .. 384 nonzeros (round 5): four waves of one register set + a partial LDS set of 32 nonzeros each, one row per CU: config
+            // C5's item rows of this length stay on chip for all of TNC's ~70 evaluations instead of re-streaming 800 bytes per nonzero
+            // for each of them (153 x the algorithmic traffic in round 4's streamed launch)
+            if (cls <= 384 && cls <= k100_max) return { 1, 0, 0, 4, 0, 32 };
         }
     } else if (PMF_LANE_F32 && s_load == 13) {   // floats: a set is 52 registers, every set in architectural registers, two waves per SIMD
         if (method == POISMF_PG) {
@@ -225,12 +235,7 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
 #ifndef PMF_LANE_PG32X4
 #define PMF_LANE_PG32X4 1   // rows of 513 .. 1024 nonzeros on FOUR waves of four sets each (three in registers, one in LDS), two such rows per CU
 #endif
-#ifndef PMF_LANE_PAIR
-#define PMF_LANE_PAIR 0   // (measured, C4 matrix: 7.05 ms against 4.86 -- a pass alone on its SIMD takes 4.8 k cycles, two of two rows side by side 5.1 k: the
-                          // passes are LATENCY-bound, and a second wave per SIMD that computes is worth more than one that gathers)
-                          // ... as TWO row streams per 8-wave workgroup: one stream's gather always runs under the other's passes (sweep_rows_paired)
-#endif
-            if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1, 0, PMF_LANE_PAIR };
+            if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1 };
             // (1025 .. 1152 nonzeros: 4.5 sets per wave do not fit; six waves x three sets, one row per CU, measured 2.50 ms against 1.85 ms
             // for reg_eval.hpp's eight-wave kernel on the 21 k such rows of the C4 matrix -- they stay there)
             if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };
@@ -270,7 +275,7 @@ struct OneLaunch {
     int team;                     // > 1: CUs per row (team launch)
     int lane_LP;                  // lane engine: nonzeros of the partial LDS set per wave
     int lane_small;               // lane engine: the two-waves-per-SIMD flavour (lane_eval.hpp, SMALL_)
-    int lane_pair;                // lane engine: two row streams per workgroup (lane_eval.hpp, NH_ = 2)
+    int lane_tx;                  // lane engine: rows of the LDS image of the tile (lane_eval.hpp, TX_)
     int lane_L, lane_A, lane_LL;  // lane_L > 0: lane-per-nonzero engine with this many lane sets per wave in VGPRs, AGPRs, LDS (nw waves per row)
     bool generic_only;
     hipStream_t main_stream, bin_stream, long_stream;

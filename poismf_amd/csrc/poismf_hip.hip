@@ -135,17 +135,6 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
     T bs[NC];
     ev.load_vec(a.bsum, bs);
     const RowDesc* desc = a.desc + a.perm_begin;
-    if constexpr (METHOD == K_PG && NW > 1) {
-        // PG does the same work on every row, the rows of a launch are sorted by length and every workgroup starts at the same time:
-        // left alone the whole chip gathers at once (at the fabric's rate) and then computes at once (with the memory system idle).
-        // A different start delay per workgroup spreads the gathers over the compute phases of the others.
-        if (a.stagger != 0) {
-            const unsigned wait = (blockIdx.x * 2654435761u >> 8) % a.stagger;
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            while ((unsigned long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-        }
-    }
-
     if constexpr (EV::PIPELINED && (EV::PIPE_MW == 1 || (EV::PIPE_MW == 2 && METHOD == K_PG))) {
         // Software pipeline over the rows of this wave.  A row costs three dependent round trips to memory -- its
         // descriptor, its indices, the factor rows those name -- and the solver in between leaves the memory pipe idle.
@@ -166,8 +155,13 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
                 if (ev.lane == 0) t = atomicAdd(a.queue, 1u);
                 return uniform(t);
             }
-            const unsigned t = r;
+            unsigned t = r;
             r += gridDim.x;
+            if constexpr (METHOD != K_PG) {
+                // (statically dealt rows have no queue head for the host to overwrite: they look at the stop word itself, one L2 read per row
+                // that nothing waits for until the ticket is used, two rows later)
+                if (a.stop != nullptr && __hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) t = 0xffffffffu;
+            }
             return t;
         };
         auto fetch = [&](unsigned t) -> RowDesc { return desc[t < a.nrows ? t : 0u]; };
@@ -212,6 +206,9 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
                 }
             }
             if (r >= a.nrows) break;
+            if constexpr (METHOD != K_PG) {
+                if (a.queue == nullptr && a.stop != nullptr && uniform(__hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) break;
+            }
             const RowDesc d = desc[r];
             r += gridDim.x;
             const unsigned nnz = uniform(d.nnz);
@@ -266,73 +263,6 @@ __device__ __forceinline__ void sweep_rows_pf(const HalfArgs<T>& a, EV& ev, unsi
     }
 }
 
-// The row loop of the PAIRED lane-engine instances (lane_eval.hpp, NH_ = 2): a workgroup of 2 NW waves, two row streams.
-// Time is cut into phases; in every phase one half of the workgroup SOLVES the row whose tile sits in its registers while the
-// other half has the tile of ITS next row in flight, and the halves swap roles at the phase boundary.  What keeps them apart is
-// the workgroup barrier the solver's passes already contain (one per evaluation, LaneEval::combine_waves): the gathering waves
-// issue their loads and then simply arrive at the same NB barriers without waiting for memory in between (a bare s_barrier:
-// no fence, the loads stay in flight); their one wait for the tile is the first use of it in the next phase.  PG only -- NB is
-// known in advance (maxupd passes, + 1 for the column sums of a weighted row) -- with rows dealt out statically.
-// Why: two independent 4-wave workgroups per CU run the same deterministic program on rows of nearly equal length and stay in
-// lockstep, and so does the whole chip -- every CU gathers at once (fabric-bound), then every CU computes with the memory system
-// idle: PG(10) on the C4 matrix cost gather time PLUS pass time.  Here one stream's gather always runs under the other's passes.
-// Half h takes rows blockIdx.x + gridDim.x (2 i + h), i = 0, 1, ..: gathered in phase 2 i + h, solved in phase 2 i + h + 1.
-template <class EV, class T, int NC, int METHOD>
-__device__ __forceinline__ void sweep_rows_paired(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
-{
-    static_assert(METHOD == K_PG && EV::NH == 2 && EV::NW > 1, "two row streams of a solver with a fixed number of barriers per row");
-    if (a.gate != nullptr && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-    ev.init(a.geom, a.F, smem);
-    T bs[NC];
-    ev.load_vec(a.bsum, bs);
-    const RowDesc* desc = a.desc + a.perm_begin;
-    const unsigned h = (unsigned)ev.half;
-    const unsigned first = blockIdx.x + gridDim.x * h, stride = 2u * gridDim.x;
-    // barriers per phase: what one solved row takes at most (every wave of the workgroup passes exactly this many per phase)
-    const unsigned NB = (unsigned)(a.P.maxupd > 0 ? a.P.maxupd : 0) + 1u;
-    // phases: stream 0 has the larger or equal number of rows n0; stream 1 ends one phase later when it has as many
-    const unsigned n0 = blockIdx.x < a.nrows ? (a.nrows - blockIdx.x - 1u) / stride + 1u : 0u;
-    const unsigned f1 = blockIdx.x + gridDim.x;
-    const unsigned n1 = f1 < a.nrows ? (a.nrows - f1 - 1u) / stride + 1u : 0u;
-    const unsigned phases = n1 == n0 && n1 > 0 ? 2u * n0 + 1u : 2u * n0;
-    auto fetch = [&](unsigned t) -> RowDesc { return desc[t < a.nrows ? t : 0u]; };   // (kept as loaded: no wait until a field is used)
-    auto start_of = [&](const RowDesc& d) { return ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo); };
-    // this stream's row being gathered / solved, and the one after it
-    unsigned t_cur = first;
-    RowDesc d_cur = fetch(t_cur), d_nxt = fetch(t_cur + stride);
-    for (unsigned p = 0; p < phases; p++) {
-        const bool gmode = ((p + h) & 1u) == 0u;
-        if (gmode) {
-            // my row's indices, then its tile -> registers: requested here, first used one phase later.  (The indices are NOT fetched
-            // a row ahead as sweep_rows does: both trips to memory lie under the other stream's solve anyway, and four more
-            // registers alive during the passes pushed the indices into scratch -- with a wait for the tile behind every reload.)
-            if (p >= h && t_cur < a.nrows) {
-                const unsigned nnz = uniform(d_cur.nnz);
-                if (nnz != 0) ev.begin_row(a.indices + start_of(d_cur), a.values + start_of(d_cur), nnz);
-            }
-            for (unsigned j = 0; j < NB; j++) asm volatile("s_barrier" ::: "memory");
-        } else {
-            ev.nbar = 0;
-            if (p > h && t_cur < a.nrows) {
-                const RowDesc d_new = fetch(t_cur + 2u * stride);   // (lands under the solve)
-                solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d_cur.lrow), uniform(d_cur.nnz));
-                t_cur += stride;
-                d_cur = d_nxt; d_nxt = d_new;
-            }
-            for (unsigned j = ev.nbar; j < NB; j++) asm volatile("s_barrier" ::: "memory");
-        }
-    }
-}
-
-template <class T, int METHOD, int KS, int LV, int NW>
-__global__ __launch_bounds__(WAVE* NW * 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void half_sweep_lane_pair_kernel(const HalfArgs<T> a)
-{
-    using EV = LaneEval<T, KS, LV, 0, 0, NW, true, false, 0, 2>;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
-    EV ev;
-    sweep_rows_paired<EV, T, EV::NC, METHOD>(a, ev, smem);
-}
-
 #ifndef PMF_TNC_PREFETCH
 #define PMF_TNC_PREFETCH 0
 #endif
@@ -365,6 +295,80 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
     if (ev.lane == 0 && ev.wid == 0)
         for (int q = 0; q < 6; q++) atomicAdd(&g_pmf_timing[q], ev.tacc[q]);
 #endif
+}
+
+// Giant rows (row_eval.hpp, TM): a team of GT_M eight-wave workgroups per row.  A workgroup joins the next open team in ARRIVAL order (whatever
+// the dispatcher and the other kernels on the chip do, a team's members are resident); the team's first member draws rows from the launch's
+// queue (longest first) and posts each ticket in the team's mailbox, the others pick it up there.  Member m streams nonzeros [m S, (m + 1) S) of
+// the row as if they were a row of their own; RowEval::team_exchange adds the members' sums per evaluation.  An exchange that times out sets the
+// launch's error word: everybody leaves, and the host re-runs the launch's rows on the one-workgroup kernel (as for the register teams).
+template <class T, int NC, int METHOD, int SL, int NW>
+__global__ __launch_bounds__(WAVE* NW) void half_sweep_giant_kernel(const HalfArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
+    using EV = RowEval<T, NC, SL, NW, PF, true>;
+    EV ev;
+    if (a.arrive != nullptr && threadIdx.x == 0) atomicAdd(a.arrive, 1u);
+    ev.init(a.geom, a.F, smem);
+    T bs[NC];
+    ev.load_vec(a.bsum, bs);
+    const RowDesc* desc = a.desc + a.perm_begin;
+    unsigned* box = ev.ticket_slot();
+    if (threadIdx.x == 0) {
+        const unsigned n = atomicAdd((unsigned*)a.team_buf, 1u);
+        box[0] = n / (unsigned)GT_M;
+        box[1] = n % (unsigned)GT_M;
+    }
+    __syncthreads();
+    const unsigned team = uniform(box[0]);
+    ev.member = (int)uniform(box[1]);
+    __syncthreads();
+    if (team >= GT_TEAMS_MAX) return;   // (the host never launches that many)
+    ev.tm_words = a.team_buf + GT_HEAD_WORDS + (size_t)team * GT_TEAM_WORDS;
+    ev.tm_err = a.team_err;
+    ev.tm_spin = a.team_spin;
+    unsigned long long* mail = ev.tm_words;   // [2]: { row number << 32 | ticket } of the row with that parity
+    constexpr unsigned END = 0xffffffffu;
+    for (unsigned rowno = 1;; rowno++) {
+        if (threadIdx.x == 0) {
+            unsigned tk = END;
+            if (ev.member == 0) {
+                tk = atomicAdd(a.queue, 1u);
+                if (tk >= a.nrows || __hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) tk = END;
+                gt_store(mail + (rowno & 1u), ((unsigned long long)rowno << 32) | tk);
+            } else {
+                // (a member whose leader has not arrived yet waits as long as other teams keep the queue moving or rows remain; the
+                // time-out applies once nothing moves)
+                unsigned seen = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned spins = 0;; spins++) {
+                    const unsigned long long v = gt_load(mail + (rowno & 1u));
+                    if ((unsigned)(v >> 32) == rowno) { tk = (unsigned)v; break; }
+                    if ((spins & 255u) == 255u) {
+                        if (__hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        const unsigned q = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (q != seen) { seen = q; spins = 0; }
+                        else if (rowno == 1u && q >= a.nrows) break;   // every row has an owner and this team never got a leader: nothing to do
+                    }
+                    if (spins > a.team_spin) { __hip_atomic_store(a.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            box[0] = tk;
+        }
+        __syncthreads();
+        const unsigned t = uniform(box[0]);
+        __syncthreads();
+        if (t >= a.nrows) break;
+        const RowDesc d = desc[t];
+        const unsigned nnz = uniform(d.nnz);
+        const unsigned long long p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
+        const unsigned S = ((nnz + (unsigned)GT_M - 1u) / (unsigned)GT_M + 63u) & ~63u;
+        const unsigned off = (unsigned)ev.member * S;
+        const unsigned mine = off < nnz ? (nnz - off < S ? nnz - off : S) : 0u;
+        ev.begin_row(a.indices + p0 + (mine ? off : 0u), a.values + p0 + (mine ? off : 0u), mine);
+        solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d.lrow), nnz);
+    }
 }
 
 // Waves per SIMD the register allocator is asked to make room for: the largest count whose VGPR budget (512 per SIMD
@@ -592,10 +596,10 @@ template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMAL
 {
     return SMALL || (LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP>::FIVE && METHOD == K_CG);
 }
-template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF = false, int LP = 0>
+template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF = false, int LP = 0, int TX = 0>
 __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(lane_two<T, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 2 : 1, lane_two<T, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
 {
-    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP>;
+    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP, TX>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
     EV ev;
     if constexpr (PF) sweep_rows_pf<EV, T, EV::NC, METHOD>(a, ev, smem);
@@ -622,6 +626,28 @@ template <int NC, int METHOD, int SL, int NW> int launch_bin(hipStream_t stream,
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW), lds, stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+template <int NC, int METHOD, int SL> int launch_giant(hipStream_t stream, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+{
+    auto kern = half_sweep_giant_kernel<real_t, NC, METHOD, SL, LONG_NW>;
+    static std::atomic<bool> attr_set[MAX_DEVICES];
+    const int dev = t_device >= 0 && t_device < MAX_DEVICES ? t_device : 0;
+    if (!attr_set[dev].load(std::memory_order_acquire) || dev != t_device) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_PER_CU));
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * LONG_NW), lds, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// giant-row teams: TNCG only (the solver whose evaluations re-stream the row; CG has its cached line search and the register teams)
+template <int NC, int SL> int launch_giant_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
+{
+    if constexpr (tu_has(K_TNCG)) {
+        if (method == POISMF_TNCG) return launch_giant<NC, K_TNCG, SL>(stream, a, lds, grid);
+    }
+    return 1;
 }
 
 template <int NC, int SL, int NW = 1> int launch_method(hipStream_t stream, int method, const HalfArgs<real_t>& a, size_t lds, unsigned grid)
@@ -710,11 +736,11 @@ template <int M, int S> int launch_team(hipStream_t stream, int method, const Ha
 }
 
 // lane-per-nonzero launches
-template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false, bool PF = false, int LP = 0> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false, bool PF = false, int LP = 0, int TX = 0> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (tu_has(METHOD)) {
-        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, PF, LP>;
-        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>;
+        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, PF, LP, TX>;
+        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP, TX>;
         // workgroups per CU: one (SMALL: two) waves per SIMD, and the LDS each takes
         const int occ = std::max(1, std::min((lane_two<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
         const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)t_num_cu * (size_t)occ * grid_mult);
@@ -723,25 +749,8 @@ template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false
         return 0;
     } else return 1;
 }
-// paired instances (two row streams per workgroup, sweep_rows_paired): one workgroup of 2 NW waves per CU
-template <int METHOD, int KS, int LV, int NW> int launch_lane_pair(hipStream_t stream, const HalfArgs<real_t>& a)
+template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, int lp, int tx, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
-    if constexpr (tu_has(METHOD) && METHOD == K_PG) {
-        auto kern = half_sweep_lane_pair_kernel<real_t, METHOD, KS, LV, NW>;
-        const unsigned grid = (unsigned)std::min<size_t>((a.nrows + 1) / 2, (size_t)t_num_cu);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW * 2), 0, stream, a);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    } else return 1;
-}
-template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, int lp, int pair, const HalfArgs<real_t>& a, unsigned grid_mult)
-{
-    if (pair) {
-        if constexpr (sizeof(real_t) == 4 && METHOD == K_PG) {
-            if (s_load == 13 && lv == 4 && la == 0 && ll == 0 && nw == 4 && lp == 0) return launch_lane_pair<METHOD, 13, 4, 4>(stream, a);
-        }
-        return 1;
-    }
     const int key = (((lv * 10 + la) * 10 + ll) * 10 + nw) * 10 + small + (lp > 0 ? 100000 : 0);
     if constexpr (sizeof(real_t) == 8) {
         if constexpr (METHOD == K_PG) return 1;
@@ -763,9 +772,12 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
                 case 112140: return launch_lane<METHOD, 25, 1, 2, 1, 4, false, false, 16>(stream, a, grid_mult);
             }
         } else if (s_load == 50) {
+            if (tx == 48 && key == 10010) return launch_lane<METHOD, 50, 1, 0, 0, 1, false, false, 0, 48>(stream, a, grid_mult);
+            if (tx == 64 && key == 10010) return launch_lane<METHOD, 50, 1, 0, 0, 1, false, false, 0, 64>(stream, a, grid_mult);
             switch (key) {
                 case 10010: return launch_lane<METHOD, 50, 1, 0, 0, 1>(stream, a, grid_mult);
                 case 10110: return launch_lane<METHOD, 50, 1, 0, 1, 1>(stream, a, grid_mult);
+                case 110040: if (lp == 32) return launch_lane<METHOD, 50, 1, 0, 0, 4, false, false, 32>(stream, a, grid_mult); break;
             }
         }
     } else {
@@ -849,16 +861,16 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
     if (o.lane_L > 0) {
-        if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
-        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
-        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
-        if (method == POISMF_EVAL) return launch_lane_shape<K_EVAL>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_pair, a, o.grid_mult);
+        if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_tx, a, o.grid_mult);
+        if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_tx, a, o.grid_mult);
+        if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_tx, a, o.grid_mult);
+        if (method == POISMF_EVAL) return launch_lane_shape<K_EVAL>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_tx, a, o.grid_mult);
         return 1;
     }
 #ifdef PMF_LANE_ONLY   // development: compile the lane-per-nonzero kernels alone (seconds instead of minutes)
     return rc;
 #else
-    if (o.team > 1) {
+    if (o.team > 1 && o.team != GT_M) {
         if (o.team == 2 && o.reg_S == 32) return launch_team<2, 32>(o.main_stream, method, a);
         if constexpr (PMF_TEAM_S36) { if (o.team == 2 && o.reg_S == 36) return launch_team<2, 36>(o.main_stream, method, a); }
         if (o.team == 3 && o.reg_S == 28) return launch_team<3, 28>(o.main_stream, method, a);
@@ -875,6 +887,15 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
         else rc = o.s_load <= REG_G ? launch_reg_steps<1>(o.bin_stream, o.reg_S, method, a, o.grid_mult)
                                     : launch_reg_steps<2>(o.bin_stream, o.reg_S, method, a, o.grid_mult);
         return rc;
+    }
+    if (o.nw > 1 && o.team == GT_M) {   // giant-row teams (row_eval.hpp, TM)
+        if (!o.generic_only && o.s_load == SPECIAL_SL_A) return launch_giant_method<SLOT_ELEMS, SPECIAL_SL_A>(o.long_stream, method, a, o.lds, o.grid);
+        if (!o.generic_only && o.s_load == SPECIAL_SL_B) return launch_giant_method<SLOT_ELEMS, SPECIAL_SL_B>(o.long_stream, method, a, o.lds, o.grid);
+        switch (o.spl) {
+            case 1: return launch_giant_method<1 * SLOT_ELEMS, 0>(o.long_stream, method, a, o.lds, o.grid);
+            case 2: return launch_giant_method<2 * SLOT_ELEMS, 0>(o.long_stream, method, a, o.lds, o.grid);
+        }
+        return 1;
     }
     if (o.nw > 1) {
 #ifndef PMF_LONG_SPECIAL

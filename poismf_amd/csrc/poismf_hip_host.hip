@@ -234,6 +234,7 @@ struct poismf_hip_session {
     unsigned* d_counter = nullptr;
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
+    unsigned long long* d_giant = nullptr;  // giant-row team launches (row_eval.hpp, GT_*): allocated by the first one
     unsigned* d_arrive = nullptr;           // workgroups of the forked long-row launch that have started (half_sweep_impl)
     unsigned long long gate_budget = 200000;   // ticks of the wall clock the hold-back gate waits at most: 2 ms (session_alloc)
     unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far
@@ -643,7 +644,7 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     if (pmf_alloc(&s->d_bsum, k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 16), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs)
+    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 24), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs; [+16] the stop word of the statically dealt CG / TNCG launches, [+17] a spare word)
     if (pmf_alloc(&s->d_arrive, sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_team_err, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
@@ -766,6 +767,7 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     pmf_free(s->d_partial, s->stream);
     pmf_free(s->d_counter, s->stream);
     pmf_free(s->d_queue, s->stream);
+    pmf_free(s->d_giant, s->stream);
     pmf_free(s->d_team, s->stream);
     pmf_free(s->d_team_err, s->stream);
     pmf_free(s->d_arrive, s->stream);
@@ -778,6 +780,8 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
 
 // the device arrays kept from finished sessions (devmem.hpp) go back to the driver
 void poismf_hip_release_cache(void) { pmf_release_cache(); }
+// how much released device memory may be kept for the next call (MB; 0 = nothing, the default); returns the previous limit
+size_t poismf_hip_set_device_cache_mb(size_t mb) { return pmf_set_cache_limit_mb(mb); }
 
 // Whoever asks for the device pointers may write through them: the padded gather copies are re-derived afterwards.
 real_t* poismf_hip_session_A(poismf_hip_session* s) { s->padded_fresh[1] = false; return s->dA; }
@@ -1025,7 +1029,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     // Consecutive bins that end up with the same tile geometry (all streamed bins; every bin of a single-pass
     // solver) are merged into one launch.
-    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0, lane_A = 0, lane_LL = 0, lane_small = 0, lane_LP = 0, lane_pair = 0; };
+    struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0, lane_A = 0, lane_LL = 0, lane_small = 0, lane_LP = 0, lane_tx = 0; };
     std::vector<Launch> launches;
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots (32 for doubles, two slots per lane), and 24-bit row ids / 32-bit
@@ -1058,22 +1062,18 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         if (single_pass) { g.resident = 0; g.prefetch = prefetch_enabled() ? 1 : 0; }  // one pass: "gather once" and "stream" are the same thing
         if (lane_ok) {
             LaneShape ls = lane_shape_for(b.cls, g.s_load, pm);
-            static const bool no_pair = getenv("POISMF_HIP_NO_PAIR") != nullptr;   // testing knob: one row stream per workgroup everywhere
-            if (no_pair) ls.pair = 0;
-            // k = 100 fp64 rows of 65 .. 128 nonzeros: the lane instance with an LDS set serves the A half only.  Measured on config C5
-            // (scripts/probes/c5_halves.py, same box): A half 159.5 -> 142.9 ms with it, but the B half 234.6 -> 296.0 -- taking its 39 k
-            // such rows out of the streamed launch leaves that launch (23 k rows of 129 .. 8192 nonzeros beside the 60 giant rows) at 277 ms
-            // instead of 232 for the same evaluations; the short rows were the tail that kept its 784 wave slots busy while the long rows
-            // drained.  Which half a row belongs to never depends on the shard.  (POISMF_HIP_K100_LANE_B=1: on both halves)
-            static const bool k100_lane_b = getenv("POISMF_HIP_K100_LANE_B") != nullptr;
+            // k = 100 fp64 rows above 64 nonzeros on the B half: rounds 3-4 left them to the streamed launch (with only the 65 .. 128-nonzero rows
+            // taken out, that launch lost the short-row tail that kept its wave slots busy: B half 234.6 -> 296.0 ms); since round 5 every row up
+            // to 384 nonzeros has a resident instance and the streamed launch keeps the 3 k rows above.  POISMF_HIP_K100_LANE_B=0: as in round 4
+            static const bool k100_lane_b = getenv("POISMF_HIP_K100_LANE_B") == nullptr || atoi(getenv("POISMF_HIP_K100_LANE_B")) != 0;
             if (sizeof(real_t) == 8 && g.s_load == 50 && b.cls > 64 && which == 0 && !k100_lane_b) ls.waves = 0;
             if (ls.waves > 0) {
-                if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp && launches.back().lane_pair == ls.pair &&
+                if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp && launches.back().lane_tx == ls.tx &&
                     launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)
                     { launches.back().count += b.count; launches.back().nnz += b.nnz; }
                 else {
                     launches.push_back({ b.begin, b.count, g, ls.waves, 0, 0, b.nnz });
-                    launches.back().lane_L = ls.lv; launches.back().lane_A = ls.la; launches.back().lane_LL = ls.ll; launches.back().lane_small = ls.small; launches.back().lane_LP = ls.lp; launches.back().lane_pair = ls.pair;
+                    launches.back().lane_L = ls.lv; launches.back().lane_A = ls.la; launches.back().lane_LL = ls.ll; launches.back().lane_small = ls.small; launches.back().lane_LP = ls.lp; launches.back().lane_tx = ls.tx;
                 }
                 continue;
             }
@@ -1118,7 +1118,13 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 continue;
             }
         }
-        if (!no_long && b.cls > long_thr) {
+        // TNCG streams a non-resident row once per evaluation (~70 of them): one wave keeps ~8 KB of gathers in flight (~4 GB/s), and once
+        // the lane engine holds every row up to 384 nonzeros the few thousand longer ones are a tail, not a crowd -- config C5, rows of
+        // 385 .. 8192 nonzeros on one wave each: 229 ms; on eight-wave workgroups: inside the 133 ms of the then-giant-row-bound launch.
+        // So TNCG's streamed rows always take the eight-wave kernel (POISMF_HIP_LONGROW_NNZ overrides; CG caches its line search, PG
+        // makes one gather per pass over the whole chip: they keep the one-wave streamed kernel below 8192 nonzeros).
+        const unsigned long_thr_here = (pm == POISMF_TNCG && !g.resident && getenv("POISMF_HIP_LONGROW_NNZ") == nullptr) ? 0u : long_thr;
+        if (!no_long && b.cls > long_thr_here) {
             // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
             // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
             g.resident = 0;
@@ -1130,10 +1136,17 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 if (cap <= 16 || lds_bytes_per_block(g, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
                 cap -= 16;
             }
-            if (!launches.empty() && launches.back().lane_L == 0 && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().begin + launches.back().count == b.begin)
+            // TNCG re-streams such a row for every evaluation: a team of GT_M workgroups per row (row_eval.hpp, TM; POISMF_HIP_NO_GIANT_TEAMS=1:
+            // one workgroup per row, rounds 1-4).  Decided by the solver alone: a row's arithmetic must not depend on its shard.
+            static const bool no_giant = getenv("POISMF_HIP_NO_GIANT_TEAMS") != nullptr;
+            static const unsigned giant_thr = getenv("POISMF_HIP_GIANT_NNZ") ? (unsigned)std::max(64, atoi(getenv("POISMF_HIP_GIANT_NNZ"))) : LONG_ROW_NNZ;   // testing knob
+            const int giant = (!no_giant && !no_team && !static_rows_ && pm == POISMF_TNCG && b.cls > giant_thr && launches.size() < (size_t)MAX_LAUNCHES - 2 &&
+                               s->num_cu >= 2 * GT_M) ? GT_M : 0;
+            if (!launches.empty() && launches.back().lane_L == 0 && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().team == giant &&
+                launches.back().begin + launches.back().count == b.begin)
                 { launches.back().count += b.count; launches.back().nnz += b.nnz; }
             else
-                launches.push_back({ b.begin, b.count, g, LONG_NW, 0, 0, b.nnz });
+                launches.push_back({ b.begin, b.count, g, LONG_NW, 0, giant, b.nnz });
             continue;
         }
         if (!launches.empty() && launches.back().lane_L == 0 && launches.back().reg_S == 0 && launches.back().geom.cap == g.cap &&
@@ -1150,6 +1163,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const int pg_lane_rows = getenv("POISMF_HIP_PG_LANE_ROWS") ? atoi(getenv("POISMF_HIP_PG_LANE_ROWS")) : 0;
     const bool pg_queue = is_pg && pg_lane_rows == 1 && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
     if (dynamic || pg_queue) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
+    if (!is_pg) HIP_TRY(hipMemsetAsync(s->d_queue + MAX_LAUNCHES + 16, 0, sizeof(unsigned), s->stream));   // the stop word of the statically dealt launches
     // the few workgroup-per-row launches of the power-law tail occupy a few dozen CUs for a long time: run them on a
     // second stream beside the other bins (fork after the column sums, join before anything reads the result)
     // Several launches per half: they also alternate between the two streams (each to the one with less work queued so
@@ -1184,7 +1198,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             char txt[192];
             const char* m = is_pg ? "pg" : p->method == POISMF_EVAL ? "eval" : pm == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
-            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP ? "+16" : "", L.nw, L.lane_pair ? ",2/SIMD,paired" : L.lane_small ? ",2/SIMD" : "", L.count);
+            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP == 32 ? "+32" : L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.lane_tx == 48 ? ",TX=48" : L.lane_tx == 64 ? ",TX=64" : "", L.count);
+            else if (L.team == GT_M && L.reg_S == 0) snprintf(txt, sizeof txt, "half_sweep_giant_kernel<%s,%s,NW=%d,M=%d,streamed cap=%d> rows=%u;", t, m, L.nw, L.team, L.geom.cap, L.count);
             else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
             else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
             else if (L.reg_S > 0) snprintf(txt, sizeof txt, "half_sweep_regw_kernel<%s,%s,S=%d,NW=%d> rows=%u;", t, m, L.reg_S, L.nw, L.count);
@@ -1194,6 +1209,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             if (char* sp = strstr(lname, " rows=")) *sp = 0;
         }
         a.queue = (dynamic || (pg_queue && L.lane_L > 0 && L.nw > 1)) ? s->d_queue + launch_no : nullptr;
+        a.stop = is_pg ? nullptr : s->d_queue + MAX_LAUNCHES + 16;   // (a word of the array the interrupt watcher overwrites: zeroed below)
         launch_no++;
         a.perm_begin = L.begin;
         a.nrows = L.count;
@@ -1210,14 +1226,24 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         const bool one_wave_reg = (L.reg_S > 0 || L.lane_L > 0) && L.nw == 1;
         if (one_wave_reg) a.queue = nullptr;
         a.team_buf = nullptr; a.team_err = s->d_team_err;
+        const bool giant = L.team == GT_M && L.reg_S == 0;
+        // (a giant-row team launch and everything that brackets it -- the copy of its rows, their restoration and re-run -- lives on the stream
+        // the long rows run on)
+        hipStream_t tst = giant ? long_stream : s->stream;
         if (L.team > 1) {
             if (a.queue == nullptr) {            // teams always draw their rows from a queue
                 a.queue = s->d_queue + MAX_LAUNCHES + (launch_no % 8);
                 HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(unsigned), s->stream));
             }
-            if (s->d_team == nullptr && pmf_alloc(&s->d_team, (size_t)TEAM_BUF_BYTES, s->stream) != hipSuccess) return 1;
-            HIP_TRY(hipMemsetAsync(s->d_team, 0, (size_t)TEAM_BUF_BYTES, s->stream));
-            a.team_buf = s->d_team;
+            if (giant) {
+                if (s->d_giant == nullptr && pmf_alloc(&s->d_giant, (size_t)GT_BUF_BYTES, s->stream) != hipSuccess) return 1;
+                HIP_TRY(hipMemsetAsync(s->d_giant, 0, (size_t)GT_BUF_BYTES, tst));
+                a.team_buf = s->d_giant;
+            } else {
+                if (s->d_team == nullptr && pmf_alloc(&s->d_team, (size_t)TEAM_BUF_BYTES, s->stream) != hipSuccess) return 1;
+                HIP_TRY(hipMemsetAsync(s->d_team, 0, (size_t)TEAM_BUF_BYTES, s->stream));
+                a.team_buf = s->d_team;
+            }
             s->team_launched = true;
             // the rows this launch starts from, in case it gives up
             const size_t need = (size_t)L.count * s->k;
@@ -1227,12 +1253,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 HIP_TRY(pmf_alloc(&s->d_team_backup, need * sizeof(real_t), s->stream));
                 s->team_backup_elems = need;
             }
-            hipLaunchKernelGGL(team_save_rows_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, (size_t)s->num_cu * 8)), dim3(256), 0, s->stream,
+            hipLaunchKernelGGL(team_save_rows_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, (size_t)s->num_cu * 8)), dim3(256), 0, tst,
                                M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, s->d_team_backup);
         }
         a.gate = nullptr;
-        static const unsigned stagger = getenv("POISMF_HIP_STAGGER") ? (unsigned)std::max(0, atoi(getenv("POISMF_HIP_STAGGER"))) : 0u;   // tuning knob (shader cycles)
-        a.stagger = is_pg && L.nw > 1 ? stagger : 0u;
         const bool is_long = L.nw > 1 && L.reg_S == 0 && L.lane_L == 0;
         a.arrive = hold_back && is_long ? s->d_arrive : nullptr;
         static const unsigned team_spin = getenv("POISMF_HIP_TEAM_SPIN_LIMIT") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_TEAM_SPIN_LIMIT"))) : TEAM_SPIN_LIMIT;   // testing knob
@@ -1247,7 +1271,13 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         // eight-wave register kernel, one workgroup per CU: 1.83 -> 1.90.)
         if (is_pg && L.lane_L > 0 && L.nw > 1 && pg_lane_rows == 0) grid_mult = 1u << 20;
         if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
-        const unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
+        unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
+        if (giant) {
+            // whole teams only: as many as the chip holds at one workgroup per CU (POISMF_HIP_GIANT_TEAMS: fewer, leaving CUs to the other bins)
+            static const unsigned want = getenv("POISMF_HIP_GIANT_TEAMS") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_GIANT_TEAMS"))) : GT_TEAMS_MAX;
+            const unsigned teams = std::max(1u, std::min(std::min((unsigned)L.count, want), std::min((unsigned)GT_TEAMS_MAX, (unsigned)s->num_cu / (unsigned)GT_M)));
+            grid = teams * (unsigned)GT_M;
+        }
         int rc = 1;
         // (with long rows on the second stream, the one-wave bins that follow go wherever less work is queued: on C5 the lane rows
         // run behind the giant rows on the second stream while the mid-length bin has the main one)
@@ -1258,14 +1288,14 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
             OneLaunch o;
-            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.lane_A = L.lane_A; o.lane_LL = L.lane_LL; o.lane_small = L.lane_small; o.lane_LP = L.lane_LP; o.lane_pair = L.lane_pair; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
+            o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.lane_A = L.lane_A; o.lane_LL = L.lane_LL; o.lane_small = L.lane_small; o.lane_LP = L.lane_LP; o.lane_tx = L.lane_tx; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
             static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
             o.generic_only = generic_only;
             o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
             o.lds = lds; o.grid = grid; o.grid_mult = grid_mult;
             o.device = s->device; o.num_cu = s->num_cu;
             // profiling sessions: events around this launch, on the stream it goes to (launch_one_here's choice)
-            hipStream_t lst = L.team > 1 || ((L.reg_S > 0 || L.lane_L > 0) && L.nw > 1) ? o.main_stream : (L.reg_S == 0 && L.lane_L == 0 && L.nw > 1 ? o.long_stream : o.bin_stream);
+            hipStream_t lst = giant ? o.long_stream : L.team > 1 || ((L.reg_S > 0 || L.lane_L > 0) && L.nw > 1) ? o.main_stream : (L.reg_S == 0 && L.lane_L == 0 && L.nw > 1 ? o.long_stream : o.bin_stream);
             LaunchRec lr{};
             if (s->profiling) {
                 HIP_TRY(hipEventCreate(&lr.t0));
@@ -1282,7 +1312,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             if (!rc && L.team > 1) {
                 // if the team launch gave up: rows back to where they started, the same rows on the streamed LDS kernel, note it
                 hipLaunchKernelGGL(team_restore_rows_kernel, dim3((unsigned)std::min<size_t>(((size_t)L.count * s->k + 255) / 256, (size_t)s->num_cu * 8)),
-                                   dim3(256), 0, s->stream, M, Mp, (int)s->ld, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k,
+                                   dim3(256), 0, tst, M, Mp, (int)s->ld, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k,
                                    s->d_team_backup, s->d_team_err);
                 HalfArgs<real_t> af = a;
                 // (a.geom is the LDS engine's geometry for the launch's longest length class: what these rows take without teams)
@@ -1290,15 +1320,16 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 af.gate = s->d_team_err;
                 af.arrive = nullptr;
                 af.queue = s->d_queue + MAX_LAUNCHES + 8 + (launch_no % 8);
-                HIP_TRY(hipMemsetAsync(af.queue, 0, sizeof(unsigned), s->stream));
+                HIP_TRY(hipMemsetAsync(af.queue, 0, sizeof(unsigned), tst));
                 OneLaunch of = o;
-                of.reg_S = 0; of.nw = 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0; of.lane_LP = 0; of.lane_pair = 0;
+                of.reg_S = 0; of.nw = giant ? LONG_NW : 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0; of.lane_LP = 0; of.lane_tx = 0;
                 of.s_load = af.geom.s_load;
-                of.bin_stream = s->stream;
-                of.lds = lds_bytes_per_block(af.geom, sizeof(real_t), 1);
-                of.grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / of.lds)) * 2);
+                of.bin_stream = tst; of.long_stream = tst;
+                of.lds = lds_bytes_per_block(af.geom, sizeof(real_t), of.nw);
+                of.grid = giant ? (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu)
+                                : (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / of.lds)) * 2);
                 rc = launch_one(p->method, of, af);
-                hipLaunchKernelGGL(team_fold_err_kernel, dim3(1), dim3(1), 0, s->stream, s->d_team_err);
+                hipLaunchKernelGGL(team_fold_err_kernel, dim3(1), dim3(1), 0, tst, s->d_team_err);
             }
             if (s->profiling) {
                 HIP_TRY(hipEventRecord(lr.t1, lst));
@@ -1485,6 +1516,89 @@ struct SigintScope {
     }
 };
 
+// ---- the interrupt reaches the row loops of CG / TNCG within a row (ref: src/poismf.c:301, :360: the reference's row loops test
+// should_stop_procedure before every row and skip the rest) -----------------------------------------------------------------------
+// Rounds 1-4 looked at the flag between half-sweeps only: up to one half (config C5: 260 ms) of latency.  CG and TNCG hand their rows
+// out through device-side queue heads (one returning atomic per row, HalfArgs::queue).  While such a run is active a host thread
+// looks at the flag every 200 us; once it is set it overwrites the session's queue heads with 0x80808080 -- every later ticket is
+// past the end of its launch, so each workgroup finishes the row it is on and leaves, exactly as the reference's threads do; rows
+// not reached keep their values (as in the reference) -- and keeps doing so (a half that had not been launched yet resets its heads
+// first) until the run ends.  Nothing is added to the kernels: the poll is the ticket they take anyway.  PG has no queue and no
+// poll (neither has the reference's pg_iteration, quirk Q8).
+struct StopPoison {   // per device, created once per process: a side stream and a pinned pattern of "past the end" queue heads
+    hipStream_t side = nullptr;
+    unsigned* pattern = nullptr;
+    bool tried = false;
+};
+inline StopPoison* stop_poison(int device)
+{
+    static StopPoison per_dev[64];
+    static std::mutex mu;
+    StopPoison& sp = per_dev[device >= 0 && device < 64 ? device : 0];
+    std::lock_guard<std::mutex> lk(mu);
+    if (!sp.tried) {
+        sp.tried = true;
+        if (hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&sp.side, hipStreamNonBlocking) == hipSuccess &&
+            hipHostMalloc((void**)&sp.pattern, sizeof(unsigned) * (MAX_LAUNCHES + 24), hipHostMallocDefault) == hipSuccess) {
+            for (int i = 0; i < MAX_LAUNCHES + 24; i++) sp.pattern[i] = 0x80808080u;
+        } else {
+            sp.side = nullptr; sp.pattern = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    return &sp;
+}
+struct StopWatch {
+    std::vector<poismf_hip_session*> ss;
+    std::vector<StopPoison*> sp;
+    std::thread th;
+    std::atomic<bool> quit{false};
+    explicit StopWatch(std::vector<poismf_hip_session*> sessions, int method) : ss(std::move(sessions))
+    {
+        if (method == POISMF_PG || getenv("POISMF_HIP_NO_ROW_INTERRUPT") != nullptr) return;
+        // (the side stream and the pinned pattern exist before the run starts: the watcher's first HIP call must not be a 200 ms one.
+        // The pattern travels by a copy from pinned memory -- the DMA engine -- not by a fill kernel, which would wait for a free CU
+        // behind the very workgroups it is meant to stop)
+        for (poismf_hip_session* s1 : ss) sp.push_back(s1 != nullptr ? stop_poison(s1->device) : nullptr);
+        for (poismf_hip_session* s1 : ss) if (s1 != nullptr) (void)hipSetDevice(s1->device);   // (back on the caller's device: one session per calling thread)
+        th = std::thread([this] {
+            // (this thread's first copy on the side stream costs ~200 ms of one-time set-up in the runtime: spent now, under the first
+            // half-sweep, into the spare word [MAX_LAUNCHES + 17] that nothing reads -- not when the signal arrives)
+            for (size_t i = 0; i < ss.size(); i++) {
+                if (ss[i] == nullptr || ss[i]->d_queue == nullptr || sp[i] == nullptr || sp[i]->side == nullptr) continue;
+                if (hipSetDevice(ss[i]->device) != hipSuccess) continue;
+                (void)hipMemcpyAsync(ss[i]->d_queue + MAX_LAUNCHES + 17, sp[i]->pattern, sizeof(unsigned), hipMemcpyHostToDevice, sp[i]->side);
+                (void)hipStreamSynchronize(sp[i]->side);
+            }
+            while (!quit.load(std::memory_order_acquire)) {
+                if (g_should_stop) {
+                    for (size_t i = 0; i < ss.size(); i++) {
+                        if (ss[i] == nullptr || ss[i]->d_queue == nullptr || sp[i] == nullptr || sp[i]->side == nullptr) continue;
+                        if (hipSetDevice(ss[i]->device) != hipSuccess) continue;
+                        (void)hipMemcpyAsync(ss[i]->d_queue, sp[i]->pattern, sizeof(unsigned) * (MAX_LAUNCHES + 17), hipMemcpyHostToDevice, sp[i]->side);
+                    }
+                    struct timespec ts = { 0, 1000000 };   // again in 1 ms: a half launched meanwhile has reset its heads
+                    nanosleep(&ts, nullptr);
+                } else {
+                    struct timespec ts = { 0, 200000 };
+                    nanosleep(&ts, nullptr);
+                }
+            }
+            for (size_t i = 0; i < ss.size(); i++) {
+                if (ss[i] == nullptr || sp[i] == nullptr || sp[i]->side == nullptr) continue;
+                (void)hipSetDevice(ss[i]->device);
+                (void)hipStreamSynchronize(sp[i]->side);
+            }
+            (void)hipGetLastError();
+        });
+    }
+    ~StopWatch()
+    {
+        quit.store(true, std::memory_order_release);
+        if (th.joinable()) th.join();
+    }
+};
+
 // The outer alternation on a session whose factors are set (ref: src/poismf.c:506-608).  Returns 0, or 1 on a device error.
 // after_first_b: called once, right after the FIRST B half has been launched (run_poismf uploads the A side's matrix then: that half needs
 // the CSC and the factors only, and the copy engine is idle while it runs)
@@ -1495,6 +1609,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
     real_t step_size = p.step_size;
     const bool tn_stop = (method == POISMF_TNCG) && p.early_stop;
     bool stopped_earlyA = false, stopped_earlyB = false;
+    StopWatch watch({ s }, method);
     for (size_t it = 0; it < numiter; it++) {
         if (g_should_stop) break;
         // quirk Q6: the divisor uses the step before halving and is reused by the A half
@@ -1697,6 +1812,7 @@ int run_poismf_multi(const std::vector<int>& devices, real_t* A, real_t* Xr, spa
         pmf_last_hip_error() = hipSuccess;
         if (setup(d)) R.fail(d);
         R.bar.arrive();
+        StopWatch watch({ R.ss[d] }, method);   // (an interrupt empties this device's row queues: the halves already enqueued end within a row)
         real_t step_size = p.step_size;
         bool stoppedA = false, stoppedB = false;
         unsigned h = 0;

@@ -55,6 +55,24 @@ constexpr unsigned TEAM_WORDS = 2 + TEAM_M_MAX + 2 * TEAM_M_MAX * TEAM_GRAN + 2;
 constexpr unsigned long long TEAM_BUF_BYTES = 8ull * (TEAM_HEAD_WORDS + (unsigned long long)TEAM_SLOTS * TEAM_WORDS);
 constexpr unsigned TEAM_SPIN_LIMIT = 1u << 20;   // polls (~1 us each) before a member gives the launch up
 
+// ---- giant rows: one STREAMED row over the LDS tiles of many CUs (RowEval, TM = true; round 5) -------------------------------
+// The power-law tail -- config C5's 60 item rows of 8 k .. 145 k nonzeros -- never fits on chip: it is re-gathered for every one of
+// TNC's evaluations, and ONE eight-wave workgroup per row moves ~70 GB/s (the biggest row alone took 120 ms of the half-sweep).
+// A team of GT_M workgroups (one per CU, formed in arrival order) takes one row: member m streams nonzeros [m S, (m + 1) S), S =
+// ceil(nnz / GT_M) rounded up to whole 64s, through its eight waves exactly as a single workgroup streams a whole row; per
+// evaluation the members' partial gradients and log-likelihood sums cross CUs as tagged 8-byte granules (as the register teams'
+// do) and are added in member order, so every wave of every member keeps the same bits and takes the same branches.
+// Buffer (8-byte words): [0] arrival counter, then per team { mailbox[2], exchange[2 parities][GT_M members][GT_GRAN granules] }.
+constexpr int GT_M = 32;                           // members of a giant-row team (a function of nothing: a row's arithmetic must not depend on its launch)
+constexpr int GT_VALS = 258;                       // doubles per exchange: a k-vector of up to 256 elements (k <= 256 fp64 / 512 fp32: two exchanges' worth is never needed) + the sum
+constexpr unsigned GT_GRAN = 2 * GT_VALS;
+constexpr unsigned GT_HEAD_WORDS = 8;
+constexpr unsigned GT_TEAM_WORDS = 2 + 2 * GT_M * GT_GRAN + 2;
+constexpr unsigned GT_TEAMS_MAX = 16;
+constexpr unsigned long long GT_BUF_BYTES = 8ull * (GT_HEAD_WORDS + (unsigned long long)GT_TEAMS_MAX * GT_TEAM_WORDS);
+__device__ __forceinline__ void gt_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long gt_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 
 // Optional phase timers (build with -DPMF_TIMING): per-wave shader-clock totals of the phases of row_eval,
 // added to a global array at kernel exit.  Slots: 0 gather, 1 phase 1, 2 coef/div, 3 phase 2, 4 combine, 5 whole kernel.
@@ -150,7 +168,7 @@ __host__ __device__ inline size_t lds_bytes_per_block(const TileGeom& g, size_t 
 // latency), eight waves on a CU approach that CU's ~24 GB/s.
 // PF: streamed rows request the NEXT chunk's factor rows (into registers) before they work on the current chunk and drop
 // them into the tile afterwards, so that a chunk's gather overlaps the previous chunk's two phases.
-template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEval {
+template <class T, int NC, int SL = 0, int NW = 1, bool PF = false, bool TM = false> struct RowEval {
     using SA = typename Slot<T>::A;
     using SU = typename Slot<T>::U;
     static constexpr int SN = Slot<T>::N;
@@ -184,7 +202,12 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     unsigned char* red_base;  // NW > 1: two sets of { [NW] partial log-likelihood sums, [NW][s_load] slots of partial gradients }
     int red_sel, red_bytes;   // the set the next combine_waves uses; bytes per set
     int wid;
-    static constexpr int member = 0;   // (teams exist in the register engine only)
+    int member = 0;                    // TM: this workgroup's place in its giant-row team (0 otherwise)
+    unsigned tm_seq = 0;               // TM: exchanges so far
+    unsigned long long* tm_words = nullptr;   // TM: this team's exchange area
+    unsigned* tm_err = nullptr;        // TM: != 0: some exchange of this launch timed out, give up
+    unsigned tm_spin = TEAM_SPIN_LIMIT;
+    static_assert(!TM || NW > 1, "giant-row teams are teams of multi-wave workgroups");
     // launch constants
     const T* F;
     int k, ldF, s_load, s_stride, cap, tail;
@@ -289,7 +312,7 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
     // registers -> global (copy 0 stores)
     __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
     {
-        if (jg == 0 && wid == 0) {
+        if (jg == 0 && wid == 0 && member == 0) {
 #pragma unroll
             for (int i = 0; i < NC; i++)
                 if (act[i]) p[elem[i]] = x[i];
@@ -658,7 +681,110 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false> struct RowEv
                     for (int e = 0; e < SN; e++) tot[s * SN + e] += act[s * SN + e] ? part[w][s].v[e] : (T)0;
                 }
             }
+            if constexpr (TM) team_exchange(tot, lsum);
         }
+    }
+    // TM, every wave of the member, after the member's own waves have been added up (tot / lsum identical in all of them): the member's
+    // sums cross the team.  Wave 0 publishes them as tagged granules { 32 data bits | exchange number } (one store each: data and tag
+    // arrive together; two alternating sets, as a member can be at most one exchange ahead of the slowest), collects the other members'
+    // and adds everything in member order; the totals reach the other waves through the cross-wave scratch, between two barriers.
+    __device__ __forceinline__ void team_exchange(T (&tot)[NC], double& lsum)
+    {
+        tm_seq++;
+        double* red_l = (double*)(red_base + red_sel * red_bytes);
+        SA* red_slots = (SA*)(red_base + red_sel * red_bytes + 16 * ((NW * sizeof(double) + 15) / 16));   // (the set the NEXT combine writes: nobody reads it now)
+        if (wid == 0) {
+            const unsigned long long tag = (unsigned long long)tm_seq << 32;
+            unsigned long long* slots = tm_words + 2 + (size_t)(tm_seq & 1u) * GT_M * GT_GRAN;
+            unsigned long long* mine = slots + (size_t)member * GT_GRAN;
+            const bool carrier = jg == 0;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+#pragma unroll
+                for (int e = 0; e < SN; e++) {
+                    if (carrier && slot_on[s]) {
+                        const unsigned long long b = __builtin_bit_cast(unsigned long long, (double)(act[s * SN + e] ? tot[s * SN + e] : (T)0));
+                        const int v = slotq[s] * SN + e;
+                        gt_store(mine + 2 * v, (b & 0xffffffffull) | tag);
+                        gt_store(mine + 2 * v + 1, (b >> 32) | tag);
+                    }
+                }
+            }
+            if (lane == 0) {
+                const unsigned long long b = __builtin_bit_cast(unsigned long long, lsum);
+                gt_store(mine + 2 * (GT_VALS - 1), (b & 0xffffffffull) | tag);
+                gt_store(mine + 2 * (GT_VALS - 1) + 1, (b >> 32) | tag);
+            }
+            T sum[NC];
+            double lt = 0.0;
+#pragma unroll
+            for (int i = 0; i < NC; i++) sum[i] = (T)0;
+            bool dead = false;
+            for (int m = 0; m < GT_M; m++) {
+                T pv[NC];
+                double pl = lsum;
+#pragma unroll
+                for (int i = 0; i < NC; i++) pv[i] = tot[i];
+                if (m != member && !dead) {
+                    const unsigned long long* theirs = slots + (size_t)m * GT_GRAN;
+                    unsigned long long lo[NC], hi[NC], l0 = tag, l1 = tag;
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool ok = true;
+#pragma unroll
+                        for (int s = 0; s < NS; s++) {
+#pragma unroll
+                            for (int e = 0; e < SN; e++) {
+                                const int i = s * SN + e;
+                                lo[i] = tag; hi[i] = tag;
+                                if (carrier && slot_on[s]) {
+                                    const int v = slotq[s] * SN + e;
+                                    lo[i] = gt_load(theirs + 2 * v);
+                                    hi[i] = gt_load(theirs + 2 * v + 1);
+                                }
+                                ok = ok && (lo[i] >> 32) == tm_seq && (hi[i] >> 32) == tm_seq;
+                            }
+                        }
+                        if (lane == 0) { l0 = gt_load(theirs + 2 * (GT_VALS - 1)); l1 = gt_load(theirs + 2 * (GT_VALS - 1) + 1); }
+                        ok = ok && (l0 >> 32) == tm_seq && (l1 >> 32) == tm_seq;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 255u) == 0 && (spins > tm_spin || __hip_atomic_load(tm_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            if (lane == 0) __hip_atomic_store(tm_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            dead = true;
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NC; i++) pv[i] = (T)__builtin_bit_cast(double, (lo[i] & 0xffffffffull) | (hi[i] << 32));
+                    pl = uniform(__builtin_bit_cast(double, (l0 & 0xffffffffull) | (l1 << 32)));
+                }
+#pragma unroll
+                for (int i = 0; i < NC; i++) sum[i] = m == 0 ? pv[i] : sum[i] + pv[i];
+                lt = m == 0 ? pl : lt + pl;
+            }
+            if (carrier) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    if (slot_on[s]) {
+                        SA v;
+#pragma unroll
+                        for (int e = 0; e < SN; e++) v.v[e] = act[s * SN + e] ? sum[s * SN + e] : (T)0;
+                        red_slots[slotq[s]] = v;
+                    }
+                }
+            }
+            if (lane == 0) red_l[0] = lt;
+        }
+        __syncthreads();
+        lsum = red_l[0];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const SA v = red_slots[slotq[s]];
+#pragma unroll
+            for (int e = 0; e < SN; e++) tot[s * SN + e] = act[s * SN + e] ? v.v[e] : (T)0;
+        }
+        __syncthreads();   // (the next combine writes this set)
     }
 
     // At the point last published with set_point:

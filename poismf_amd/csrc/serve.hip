@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/poismf_hip.h"
+#include "devmem.hpp"
 
 namespace {
 
@@ -60,7 +61,7 @@ __global__ void mask_kernel(const unsigned* excl, size_t n_excl, real_t* scores)
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
+    bool alloc(size_t bytes) { return pmf_malloc_retry(&p, bytes ? bytes : 16) == hipSuccess; }
     template <class U> U* as() { return (U*)p; }
 };
 

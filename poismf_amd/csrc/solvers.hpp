@@ -23,10 +23,6 @@ namespace pmf {
 
 template <class T> __device__ __forceinline__ bool not_finite(T v) { return isnan(v) || isinf(v); }
 
-// engines that can fetch part of the NEXT row's tile while the current row is being solved say so by having prefetch_tile()
-template <class E, class = void> struct has_prefetch_tile : std::false_type {};
-template <class E> struct has_prefetch_tile<E, std::void_t<decltype(std::declval<E&>().prefetch_tile())>> : std::true_type {};
-
 // What a row's solver decided, for tests that pin the decisions and not only the result (the reference hands the same numbers
 // back from minimize_nonneg_cg -- niter, nfeval, ref: src/nonnegcg.c:177-189 -- and from tnc -- nfeval, niter, rc, ref:
 // src/tnc.c:251-260; cg_iteration / tncg_iteration drop them).  CG rc: 0 |g.d| <= tol, 1 evaluation budget, 2 iteration
@@ -50,8 +46,6 @@ __device__ __forceinline__ void pg_row(EV& ev, const RowParams<T>& P, T (&x)[NC]
             x[i] = x[i] * P.cnst_div;                              // a *= 1 / (1 + 2 l2 step)
             x[i] = (x[i] > (T)0) ? x[i] : (T)0;                    // a = max(a, 0)
         }
-        // (engines that can: the next row's tile starts travelling now, under the remaining passes of this one)
-        if constexpr (has_prefetch_tile<EV>::value) { if (u == 0) ev.prefetch_tile(); }
         PMF_STAMP(ev, 9);
     }
 }
@@ -100,6 +94,15 @@ __device__ __forceinline__ T fun_and_grad(EV& ev, const RowParams<T>& P, const T
                                           const T (&a)[NC], T (&g)[NC])
 {
     ev.set_point(a);
+#ifdef PMF_DUP_EVAL   // development: every TNC evaluation made twice (same results and decisions): the difference to the plain build is what the evaluations cost
+    {
+        T g2[NC];
+        PMF_EW g2[i] = (T)0;
+        const double l2nd = ev.template eval<true, true>((T)-1, g2);
+        asm volatile("" :: "v"(g2[0]), "v"(l2nd));
+        ev.n_eval--;
+    }
+#endif
     PMF_EW g[i] = (T)0;
     const T lsum = (T)ev.template eval<true, true>((T)-1, g);
     const T two_l2 = (T)(2. * (double)P.l2);
@@ -645,8 +648,33 @@ template <class T, int NC, class EV> struct Tnc {
         PMF_EW out[i] = gamma * hv[i] + delta * sj[i] + beta * hy[i];
     }
 
-    // ref: :1444-1528
-    static __device__ __forceinline__ void msolve(const EV& ev, const ST& s, const T (&g)[NC], T (&y)[NC], bool upd1,
+    // ref: :1444-1528.  The reference recomputes everything on every call; within one tnc_direction the preconditioner's
+    // inputs (diagb, sk, yk, sr, yr, yksk, yrsr) do not change, so what does not depend on the vector being solved for -- 1 / diagb,
+    // H yk (after its own BFGS update), yk.H yk and yr.H yr -- is computed ONCE per direction (msolve_prepare) with the very
+    // operations the reference applies, in its order: same bits, five dot products, two ssbfgs scalar blocks and a vector
+    // division fewer per CG iteration.
+    struct MsolveInv { T rd[NC], hyk[NC]; T ykhyk, yrhyr; };
+    static __device__ __forceinline__ void msolve_prepare(const EV& ev, const ST& s, MsolveInv& inv, bool upd1, T yksk, T yrsr, bool lreset)
+    {
+        (void)yksk;
+        if (upd1) return;
+        PMF_EW {
+            inv.rd[i] = 1.0 / s.diagb[i];
+            inv.hyk[i] = s.yk[i] * inv.rd[i];
+        }
+        if (lreset) {
+            inv.ykhyk = ev.dot(s.yk, inv.hyk);
+            return;
+        }
+        T hyr[NC];
+        PMF_EW hyr[i] = s.yr[i] * inv.rd[i];
+        inv.yrhyr = ev.dot(s.yr, hyr);
+        const T yksr = ev.dot(s.yk, s.sr);
+        const T ykhyr = ev.dot(s.yk, hyr);
+        ssbfgs(s.sr, inv.hyk, hyr, yrsr, inv.yrhyr, yksr, ykhyr, inv.hyk);
+        inv.ykhyk = ev.dot(inv.hyk, s.yk);
+    }
+    static __device__ __forceinline__ void msolve(const EV& ev, const ST& s, const MsolveInv& inv, const T (&g)[NC], T (&y)[NC], bool upd1,
                                                   T yksk, T yrsr, bool lreset)
     {
         if (upd1) {
@@ -654,33 +682,19 @@ template <class T, int NC, class EV> struct Tnc {
             return;
         }
         const T gsk = ev.dot(g, s.sk);
-        T hg[NC], hyk[NC], hyr[NC];
+        T hg[NC];
+        PMF_EW hg[i] = g[i] * inv.rd[i];
         if (lreset) {
-            PMF_EW {
-                const T rd = 1.0 / s.diagb[i];
-                hg[i] = g[i] * rd;
-                hyk[i] = s.yk[i] * rd;
-            }
-            const T ykhyk = ev.dot(s.yk, hyk);
-            const T ghyk = ev.dot(g, hyk);
-            ssbfgs(s.sk, hg, hyk, yksk, ykhyk, gsk, ghyk, y);
+            const T ghyk = ev.dot(g, inv.hyk);
+            ssbfgs(s.sk, hg, inv.hyk, yksk, inv.ykhyk, gsk, ghyk, y);
         } else {
-            PMF_EW {
-                const T rd = 1.0 / s.diagb[i];
-                hg[i] = g[i] * rd;
-                hyk[i] = s.yk[i] * rd;
-                hyr[i] = s.yr[i] * rd;
-            }
+            T hyr[NC];
+            PMF_EW hyr[i] = s.yr[i] * inv.rd[i];
             const T gsr = ev.dot(g, s.sr);
             const T ghyr = ev.dot(g, hyr);
-            const T yrhyr = ev.dot(s.yr, hyr);
-            ssbfgs(s.sr, hg, hyr, yrsr, yrhyr, gsr, ghyr, hg);
-            const T yksr = ev.dot(s.yk, s.sr);
-            const T ykhyr = ev.dot(s.yk, hyr);
-            ssbfgs(s.sr, hyk, hyr, yrsr, yrhyr, yksr, ykhyr, hyk);
-            const T ykhyk = ev.dot(hyk, s.yk);
-            const T ghyk = ev.dot(hyk, g);
-            ssbfgs(s.sk, hg, hyk, yksk, ykhyk, gsk, ghyk, y);
+            const T ghyk = ev.dot(inv.hyk, g);
+            ssbfgs(s.sr, hg, hyr, yrsr, inv.yrhyr, gsr, ghyr, hg);
+            ssbfgs(s.sk, hg, inv.hyk, yksk, inv.ykhyk, gsk, ghyk, y);
         }
     }
 
@@ -748,11 +762,13 @@ template <class T, int NC, class EV> struct Tnc {
         const T rhsnrm = gnorm, tol = 1e-12;
         T qold = 0.0, rzold = 0.0;
         init_precond(ev, s, lreset, yksk, yrsr, upd1);
+        MsolveInv inv;
+        msolve_prepare(ev, s, inv, upd1, yksk, yrsr, lreset);
         PMF_EW { s.r[i] = -s.g[i]; s.v[i] = 0.0; zsol[i] = 0.0; }
 
         for (int it = 0; it < maxCGit; it++) {
             project(s, s.r);
-            msolve(ev, s, s.r, s.zk, upd1, yksk, yrsr, lreset);
+            msolve(ev, s, inv, s.r, s.zk, upd1, yksk, yrsr, lreset);
             project(s, s.zk);
             const T rz = ev.dot(s.r, s.zk);
             if ((rz / rhsnrm < tol) || (s.nfeval >= (s.maxnfeval - 1))) {
@@ -773,7 +789,7 @@ template <class T, int NC, class EV> struct Tnc {
             const T vgv = ev.dot(s.v, s.gv);
             if (vgv / rhsnrm < tol) {
                 if (it == 0) {
-                    msolve(ev, s, s.g, zsol, upd1, yksk, yrsr, lreset);
+                    msolve(ev, s, inv, s.g, zsol, upd1, yksk, yrsr, lreset);
                     PMF_EW zsol[i] = -zsol[i];
                     project(s, zsol);
                 }
@@ -781,7 +797,7 @@ template <class T, int NC, class EV> struct Tnc {
             }
             {   // diagonalScaling, ref: :1347-1362
                 const T vr = 1.0 / ev.dot(s.v, s.r);
-                const T ivgv = 1.0 / ev.dot(s.v, s.gv);
+                const T ivgv = 1.0 / vgv;                                 // (the reference takes v.gv a second time: the same sum)
                 PMF_EW {
                     s.emat[i] += -s.r[i] * s.r[i] * vr + s.gv[i] * s.gv[i] * ivgv;
                     s.emat[i] = ((double)s.emat[i] <= 1e-6) ? (T)1. : s.emat[i];
@@ -922,10 +938,10 @@ template <class T, int NC, class EV> struct Tnc {
         PMF_EW { s.diagb[i] = 1.0; s.sk[i] = 0; s.yk[i] = 0; s.sr[i] = 0; s.yr[i] = 0; }
 
         for (;;) {
-            if (ev.nrm2(s.g) <= pgtol * fscale) { rc = T_LOCALMINIMUM; break; }   // ref: :700-712
+            T newscale = ev.nrm2(s.g);                                    // (taken twice in the reference, ref: :700, :720: the same sum)
+            if (newscale <= pgtol * fscale) { rc = T_LOCALMINIMUM; break; }   // ref: :700-712
             if (s.nfeval >= s.maxnfeval) { rc = T_MAXFUN; break; }
-
-            T newscale = ev.nrm2(s.g);                                    // ref: :720-746
+                                                                          // ref: :720-746
             if ((newscale > EPSV) && (d_abs(d_log10(newscale)) > rescale)) {
                 newscale = 1.0 / newscale;
                 f *= newscale; fscale *= newscale; gnorm *= newscale;

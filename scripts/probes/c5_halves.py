@@ -24,3 +24,6 @@ for w in (0, 1):
     print("half", "AB"[w ^ 1] if False else ("B" if w == 0 else "A"), "ms per half-sweep %.1f" % (ms / timed), "evaluations (last sweep) %d, nnz x evaluations %.3e" % (d["evaluations"], d["nnz_evaluations"]))
     for L in s.launch_profile(w):
         print("    %-70s rows=%-7d nnz=%-9d ms=%.1f" % (L["kernel"][:70], L["rows"], L["nnz"], L["ms"] / L["calls"]))
+import hashlib
+A, B = s.get_factors()
+print("factors sha256", hashlib.sha256(A.tobytes()).hexdigest()[:16], hashlib.sha256(B.tobytes()).hexdigest()[:16], "(bit-identical builds print the same)")

@@ -82,19 +82,25 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, method, is_float, balanced, numiter, outdir, nseg=(1, 1)):
+def _problem(shape):
+    if shape == "c5":   # config-C5-shaped: power-law item degrees, short user rows: the nnz-balanced ranges of eight ranks are very unequal
+        return H.small_problem(400, 300, 9000, 6, False, seed=13, powerlaw=True, empty_rows=(4, 250)), (400, 300)
+    return H.small_problem(90, 70, 1500, 6, False, seed=11, powerlaw=True, empty_rows=(4,)), (90, 70)
+
+
+def _worker(rank, world, port, method, is_float, balanced, numiter, outdir, nseg=(1, 1), shape="small"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    csr, csc, A0, B0 = H.small_problem(90, 70, 1500, 6, is_float, seed=11, powerlaw=True, empty_rows=(4,))
+    (csr, csc, A0, B0), (dimA, dimB) = _problem(shape)
     l2, maxupd, _ = harness.auto_defaults(method, 6)
     if method == "tncg":
         maxupd = 40
     if balanced:
         rA, rB = pdist.balanced_ranges(csr[2], world), pdist.balanced_ranges(csc[2], world)
     else:
-        rA, rB = pdist.equal_ranges(90, world), pdist.equal_ranges(70, world)
+        rA, rB = pdist.equal_ranges(dimA, world), pdist.equal_ranges(dimB, world)
     be = OracleShardBackend(csr, csc, A0, B0, method, l2, maxupd, rA[rank], rB[rank], is_float, nseg=nseg)
-    alt = pdist.ShardedAlternation(be, rA, rB, method, l2, 1e-7, early_stop=(method == "tncg"), dims=(90, 70))
+    alt = pdist.ShardedAlternation(be, rA, rB, method, l2, 1e-7, early_stop=(method == "tncg"), dims=(dimA, dimB))
     for _ in range(numiter):
         if not alt.sweep():
             break
@@ -118,6 +124,28 @@ def test_world2_gloo_matches_unsharded_oracle(tmp_path, method, balanced, nseg):
     A, B = A0.copy(), B0.copy()
     bindings.Oracle(is_float).run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], l2, 0.0, 1.0, 1e-7, method,
                                          True, numiter, maxupd, method == "tncg", False)
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        assert np.array_equal(z["A"], A) and np.array_equal(z["B"], B)
+
+
+@pytest.mark.parametrize("method", ["pg", "tncg"])
+def test_world8_gloo_on_power_law_ranges_matches_unsharded_oracle(tmp_path, method):
+    """The node the north-star names has eight GPUs: EIGHT gloo ranks on a config-C5-shaped matrix (power-law item degrees: the
+    nnz-balanced B ranges run from a handful of rows to hundreds), the A half exchanged in two segments -- the 56 point-to-point
+    transfers of a half, unequal (and possibly empty) shards, the summed early-stop counter.  Bit for bit the unsharded oracle."""
+    world, numiter = 8, 2
+    mp.spawn(_worker, args=(world, _free_port(), method, False, True, numiter, str(tmp_path), (1, 2), "c5"), nprocs=world, join=True)
+    (csr, csc, A0, B0), _ = _problem("c5")
+    rB = pdist.balanced_ranges(csc[2], world)
+    sizes = [e - b for b, e in rB]
+    assert max(sizes) >= 8 * max(1, min(sizes))          # (the ranges ARE very unequal: what this test is for)
+    l2, maxupd, _ = harness.auto_defaults(method, 6)
+    if method == "tncg":
+        maxupd = 40
+    A, B = A0.copy(), B0.copy()
+    bindings.Oracle(False).run_poismf(A, csr[0], csr[2], csr[1], B, csc[0], csc[2], csc[1], l2, 0.0, 1.0, 1e-7, method,
+                                      True, numiter, maxupd, method == "tncg", False)
     for r in range(world):
         z = np.load(tmp_path / f"r{r}.npz")
         assert np.array_equal(z["A"], A) and np.array_equal(z["B"], B)

@@ -1,0 +1,109 @@
+"""Giant rows shared by a TEAM of workgroups (poismf_amd/csrc/row_eval.hpp, TM; poismf_hip.hip, half_sweep_giant_kernel): TNCG re-streams a
+row that fits no CU once per evaluation, and config C5's item rows reach 1.4e5 nonzeros -- one eight-wave workgroup per row left the biggest
+row alone at 120 ms per half-sweep.  A team of 32 workgroups streams one row (member m its 1/32nd), the partial sums cross CUs per evaluation.
+The threshold is 8192 nonzeros; POISMF_HIP_GIANT_NNZ lowers it so that small matrices reach the path (a knob read once per process: children).
+Through the C-ABI against the oracle; against the one-workgroup path; repeatability; and the fallback when a team gives up.  Needs an MI355X."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from poismf_amd import harness
+from tests import helpers as H
+from tests.test_gpu_parity import compare, oracle_run
+from tests.test_gpu_regtile import ragged_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENGTHS = [40, 100, 257, 300, 700, 1000, 1023, 2500, 5000, 9000] + [1500] * 12     # 20 rows above the lowered threshold: more rows than teams
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from poismf_amd import api
+from tests.test_gpu_giant import LENGTHS
+from tests.test_gpu_regtile import ragged_problem
+from tests.test_gpu_parity import gpu_run
+k, prec = {k}, {prec}
+csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, k, prec, seed=33)
+outs = []
+for _ in range({repeat}):
+    A, B, args = gpu_run(csr, csc, A0, B0, "tncg", 2, k, maxupd={maxupd}, w_mult={w})
+    outs.append(np.concatenate([A.ravel(), B.ravel()]).astype(np.float64))
+s = api.Session(csr, csc, A0.shape[0], B0.shape[0], k, prec)
+s.set_factors(A0, B0)
+s.half_sweep(1, s.make_params("tncg", 1e3, maxupd=20), 1e-7, 1.0)
+print("PLAN", " ".join(name for name, _ in s.plan(1)))
+s.close()
+np.save({out!r}, np.stack(outs))
+"""
+
+
+def run_child(tmp_path, tag, env, k=100, prec=False, repeat=1, maxupd=300, w=1.0):
+    out = str(tmp_path / f"{tag}.npy")
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, k=k, prec=prec, repeat=repeat, maxupd=maxupd, w=w)], check=True,
+                       env=e, cwd=ROOT, timeout=900, capture_output=True, text=True)
+    plan = [l for l in r.stdout.splitlines() if l.startswith("PLAN")][0]
+    return np.load(out), plan, r.stderr
+
+
+NO_TEAMS = any(os.environ.get(v) for v in ("POISMF_HIP_NO_TEAM", "POISMF_HIP_NO_GIANT_TEAMS", "POISMF_HIP_STATIC_ROWS", "POISMF_HIP_NO_LONGROW"))
+
+
+@pytest.mark.parametrize("k,prec,w", [(100, False, 1.0), (100, False, 3.0), (50, False, 1.0), (20, False, 1.0)])
+def test_giant_team_rows_vs_oracle_and_repeatable(tmp_path, k, prec, w):
+    res, plan, _ = run_child(tmp_path, "team", {"POISMF_HIP_GIANT_NNZ": "256"}, k=k, prec=prec, repeat=3, w=w)
+    if not NO_TEAMS:
+        assert "half_sweep_giant_kernel<double,tncg,NW=8,M=32" in plan, plan
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])      # teams form in arrival order; the bits do not care
+    csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, k, prec, seed=33)
+    l2, _, _ = harness.auto_defaults("tncg", k)
+    args = dict(l2_reg=l2, l1_reg=0.0, w_mult=w, step_size=1e-7, limit_step=True, niter=2, maxupd=300, early_stop=True, reuse_prev=False)
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, "tncg", args)
+    nA = A0.size
+    A, B = res[0][:nA].reshape(A0.shape), res[0][nA:].reshape(B0.shape)
+    assert not A[-1].any()
+    compare(prec, "tncg", csr, args, A, B, Ar, Br, converged=False)
+
+
+def test_giant_team_fp32_is_finite_and_close_to_the_one_workgroup_path(tmp_path):
+    """fp32 TNC is chaotic in the reference itself: the team path is held to the one-workgroup path one-sidedly"""
+    team, plan, _ = run_child(tmp_path, "team", {"POISMF_HIP_GIANT_NNZ": "256"}, k=50, prec=True)
+    one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_NO_GIANT_TEAMS": "1"}, k=50, prec=True)
+    if not NO_TEAMS:
+        assert "half_sweep_giant_kernel<float,tncg" in plan, plan
+    csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, 50, True, seed=33)
+    l2, _, _ = harness.auto_defaults("tncg", 50)
+    nA = A0.size
+    obj = []
+    for r in (team[0], one[0]):
+        assert np.isfinite(r).all() and r.min() >= 0
+        obj.append(harness.poisson_objective(r[:nA].reshape(A0.shape).astype(np.float32), r[nA:].reshape(B0.shape).astype(np.float32), csr, l2, 0.0, 1.0))
+    assert obj[0] <= obj[1] + 1e-2 * abs(obj[1])
+
+
+def test_giant_team_and_one_workgroup_paths_agree(tmp_path):
+    team, _, _ = run_child(tmp_path, "team", {"POISMF_HIP_GIANT_NNZ": "256"})
+    one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_NO_GIANT_TEAMS": "1"})
+    csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, 100, False, seed=33)
+    l2, _, _ = harness.auto_defaults("tncg", 100)
+    nA = A0.size
+    o = [harness.poisson_objective(r[0][:nA].reshape(A0.shape), r[0][nA:].reshape(B0.shape), csr, l2, 0.0, 1.0) for r in (team, one)]
+    assert abs(o[0] - o[1]) <= 5e-5 * abs(o[1]), o          # two summation orders of the same fp64 arithmetic (mid-path bound of compare())
+
+
+def test_a_giant_team_that_gives_up_is_rerun_by_one_workgroup_per_row(tmp_path):
+    """POISMF_HIP_TEAM_SPIN_LIMIT=1: members give up waiting for their ticket at once, the launch sets the error word, the host puts the rows
+    back where they started and runs them on the one-workgroup kernel.  The call returns 0, says so on stderr, and the factors are those of
+    POISMF_HIP_NO_GIANT_TEAMS=1 bit for bit (the same kernel on the same rows from the same starting point)."""
+    if NO_TEAMS:
+        pytest.skip("no giant-row team launches under this knob")
+    gave, _, err = run_child(tmp_path, "gave_up", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_TEAM_SPIN_LIMIT": "1"})
+    one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_NO_GIANT_TEAMS": "1"})
+    assert "re-run on the streamed path" in err, err
+    assert np.isfinite(gave).all()
+    assert np.array_equal(gave, one)

@@ -556,3 +556,50 @@ def test_coo_session_rejects_indices_outside_the_matrix():
         t = synth.Triplets(np.array(bad_row, np.int64), np.array(bad_col, np.int64), np.ones(3), (3, 3))
         with pytest.raises(ValueError):
             api.Session.from_coo(t, 5, False)
+
+
+def test_sigint_ends_a_half_sweep_within_a_row():
+    """ref: src/poismf.c:301, :360 -- the reference's CG / TNCG row loops test the interrupt flag before every row.  Rounds 1-4 looked at
+    it between half-sweeps only (config C5: up to 260 ms).  Since round 5 a host thread empties the device-side row queues when the
+    flag is set: every workgroup finishes the row it is on and leaves.  C5-shaped rows (user rows of ~48 nonzeros, item rows of ~100 with
+    mild skew, k = 100, tncg fp64): a half-sweep takes 100 ms and more, the call must be back within 50 ms of the signal."""
+    import signal
+    import threading
+    import time as _time
+    from poismf_amd import synth
+    coo = synth.lastfm_like_coo(nusers=250000, nitems=110000, mean_deg=47, zipf_a=0.15, seed=3)
+    dimA, dimB = coo.shape
+    s = api.Session.from_coo(coo, 100, False)
+    A0, B0 = harness.initialize_matrices(dimA, dimB, 100, False, 1)
+    p = s.make_params("tncg", 1e3, maxupd=1500, reuse_prev=True, early_stop=False)
+    # how long an uninterrupted sweep takes here
+    s.set_factors(A0, B0)
+    t0 = _time.perf_counter()
+    assert s.run(p, 2) == 0
+    sweep_s = (_time.perf_counter() - t0) / 2
+    assert sweep_s > 0.15, sweep_s                      # (otherwise the test shows nothing)
+    prev = signal.signal(signal.SIGINT, lambda *a: None)
+    try:
+        lat = []
+        for delay in (0.31 * sweep_s, 0.83 * sweep_s, 1.57 * sweep_s):
+            s.set_factors(A0, B0)
+            fired = []
+
+            def fire():
+                _time.sleep(delay)
+                fired.append(_time.perf_counter())
+                os.kill(os.getpid(), signal.SIGINT)
+            th = threading.Thread(target=fire)
+            th.start()
+            rc = s.run(p, 40)
+            t_back = _time.perf_counter()
+            th.join()
+            assert rc == 2
+            lat.append(t_back - fired[0])
+            A, B = s.get_factors()
+            assert np.isfinite(A).all() and np.isfinite(B).all() and not np.array_equal(B, B0)   # (the state reached stays valid)
+        print("sweep %.0f ms; interrupt latencies (ms): %s" % (sweep_s * 1e3, ", ".join("%.1f" % (v * 1e3) for v in lat)))
+        assert max(lat) < 0.050, lat
+    finally:
+        signal.signal(signal.SIGINT, prev)
+        s.close()

@@ -216,32 +216,24 @@ def test_weighted_rows_on_both_sides_of_every_hand_over(prec, method):
         compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
 
 
-PAIR_CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, {root!r})
-from tests.test_gpu_regtile import ragged_problem
-from tests.test_gpu_parity import gpu_run
-rng = np.random.default_rng(7)
-lengths = [int(v) for v in rng.integers(513, 1025, size={nrows})] + [513, 1024, 1024, 600]
-csr, csc, A0, B0 = ragged_problem(lengths, 3000, 50, True, seed=21)
-A, B, _ = gpu_run(csr, csc, A0, B0, "pg", 2, 50, l2_reg=1e3, step_size=1e-9, maxupd={maxupd}, w_mult={w})
-np.save({out!r}, np.concatenate([A.ravel(), B.ravel()]))
-"""
+K100_LENGTHS = [1, 16, 17, 40, 47, 48, 49, 60, 63, 64, 65, 100, 127, 128, 129, 130, 200, 255, 256, 257, 300, 320, 321, 383, 384, 385, 500, 700]
 
 
-@pytest.mark.parametrize("nrows,maxupd,w", [(3, 10, 1.0), (41, 3, 1.0), (700, 10, 1.0), (41, 4, 3.0)])
-def test_paired_row_streams_match_one_stream_per_workgroup_bit_for_bit(nrows, maxupd, w, tmp_path):
-    """PG fp32, k = 50, rows of 513 .. 1024 nonzeros: the lane instance with TWO row streams per workgroup (lane_eval.hpp NH_ = 2,
-    sweep_rows_paired: one stream gathers under the other's passes, the halves meet at the passes' own barriers) against the same
-    instance with one stream per workgroup (POISMF_HIP_NO_PAIR=1).  Same arithmetic in the same order: the same bits -- for fewer
-    rows than streams, an odd number of rows per workgroup, several rounds per stream (700 rows on 256 CUs), and with weights (one
-    more barrier per row: the column sums of the tile)."""
-    res = {}
-    for tag, env in (("pair", {}), ("single", {"POISMF_HIP_NO_PAIR": "1"})):
-        out = str(tmp_path / f"{tag}.npy")
-        e = dict(os.environ); e.update(env)
-        subprocess.run([sys.executable, "-c", PAIR_CHILD.format(root=ROOT, nrows=nrows, maxupd=maxupd, w=w, out=out)], check=True, env=e,
-                       cwd=ROOT, timeout=600)
-        res[tag] = np.load(out)
-    assert np.isfinite(res["pair"]).all() and res["pair"].any()
-    assert np.array_equal(res["pair"], res["single"])
+@pytest.mark.parametrize("method,w", [("tncg", 1.0), ("cg", 1.0), ("tncg", 3.0), ("cg", 3.0)])
+def test_k100_fp64_lane_instances_on_both_sides_of_every_hand_over(method, w):
+    """k = 100 fp64 (config C5's shape) -- the lane engine's instances of round 5 against the oracle, rows on either side of every
+    hand-over: <= 48 / <= 64 nonzeros with the gradient accumulated from the row-major LDS image (lane_eval.hpp, TX_ = 48 / 64; the tile
+    lives in LDS only), 65 .. 128 one register set + one LDS set, 129 .. 384 four waves of one register set + a partial LDS set of 32
+    nonzeros (one row per CU), above that the streamed engine.  With weights the per-row constant term takes the column sums of the
+    tile from the same image.  And the same rows three times give the same bits."""
+    k = 100
+    csr, csc, A0, B0 = ragged_problem(K100_LENGTHS, 3000, k, False, seed=17)
+    kw = dict(w_mult=w)
+    if method == "tncg":
+        kw.update(maxupd=300)
+    A, B, args = gpu_run(csr, csc, A0, B0, method, 2, k, **kw)
+    Ar, Br = oracle_run(False, csr, csc, A0, B0, method, args)
+    assert not A[-1].any()
+    compare(False, method, csr, args, A, B, Ar, Br, converged=False)
+    A2, B2, _ = gpu_run(csr, csc, A0, B0, method, 2, k, **kw)
+    assert np.array_equal(A, A2) and np.array_equal(B, B2)

@@ -75,10 +75,11 @@ np.save({out!r}, np.concatenate(outs))
 
 
 def test_kept_device_arrays_leave_no_trace(tmp_path):
-    """devmem.hpp keeps the device arrays of finished calls for the next call of the same sizes: same bits as with the list off, and
-    the same problem gives the same bits the first and the last time."""
+    """A caller that opts in (POISMF_HIP_DEVICE_CACHE_MB; off by default since round 5) has devmem.hpp keep the device arrays of finished
+    calls for the next call of the same sizes: same bits as with the list off, and the same problem gives the same bits the first and
+    the last time."""
     res = {}
-    for tag, env in {"kept": {}, "off": {"POISMF_HIP_DEVICE_CACHE_MB": "0"}, "tiny": {"POISMF_HIP_DEVICE_CACHE_MB": "40"}}.items():
+    for tag, env in {"kept": {"POISMF_HIP_DEVICE_CACHE_MB": "16384"}, "off": {}, "tiny": {"POISMF_HIP_DEVICE_CACHE_MB": "40"}}.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
         e.update(env)
@@ -105,16 +106,62 @@ np.save({out!r}, np.concatenate([A.ravel(), B.ravel()]))
 
 def test_pg_row_hand_out_leaves_no_trace(tmp_path):
     """PG's multi-wave lane launches hand their rows out one per workgroup (round 4); persistent workgroups on the queue or with static shares
-    (POISMF_HIP_PG_LANE_ROWS = 1 / 2), another grid size or a start delay must give the same bits: a row's arithmetic depends on its length
+    (POISMF_HIP_PG_LANE_ROWS = 1 / 2) or another grid size must give the same bits: a row's arithmetic depends on its length
     class alone."""
     res = {}
     for tag, env in {"fresh": {}, "queue": {"POISMF_HIP_PG_LANE_ROWS": "1"}, "static": {"POISMF_HIP_PG_LANE_ROWS": "2"},
-                     "static_g7": {"POISMF_HIP_PG_LANE_ROWS": "2", "POISMF_HIP_GRID_MULT": "7"}, "stagger": {"POISMF_HIP_STAGGER": "5000"}}.items():
+                     "static_g7": {"POISMF_HIP_PG_LANE_ROWS": "2", "POISMF_HIP_GRID_MULT": "7"}}.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
         e.update(env)
         subprocess.run([sys.executable, "-c", CHILD_HANDOUT.format(root=ROOT, out=out)], check=True, env=e, cwd=ROOT, timeout=600)
         res[tag] = np.load(out)
     assert np.isfinite(res["fresh"]).all() and res["fresh"].any()
-    for tag in ("queue", "static", "static_g7", "stagger"):
+    for tag in ("queue", "static", "static_g7"):
         assert np.array_equal(res[tag], res["fresh"]), tag
+
+
+CHILD_LIMIT = r"""
+import sys, numpy as np, ctypes
+sys.path.insert(0, {root!r})
+from tests import helpers as H
+from tests.test_gpu_parity import gpu_run
+from poismf_amd import api
+hip = ctypes.CDLL("libamdhip64.so")
+def free_mb():
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+    return f.value >> 20
+csr, csc, A0, B0 = H.small_problem(60000, 20000, 6000000, 50, False, seed=5)
+outs, free = [], []
+gpu_run(csr, csc, A0, B0, "pg", 1, 50)          # (device up, pinned chunks and streams allocated: what the process keeps either way)
+free.append(free_mb())
+A, B, _ = gpu_run(csr, csc, A0, B0, "pg", 1, 50)
+outs.append(np.concatenate([A.ravel(), B.ravel()]))
+free.append(free_mb())                          # default: nothing of the call is left on the device
+assert api.set_device_cache_mb(4096, False) == {{False: 0}}
+A, B, _ = gpu_run(csr, csc, A0, B0, "pg", 1, 50)
+outs.append(np.concatenate([A.ravel(), B.ravel()]))
+free.append(free_mb())                          # opted in: the call's large arrays are still allocated
+A, B, _ = gpu_run(csr, csc, A0, B0, "pg", 1, 50)
+outs.append(np.concatenate([A.ravel(), B.ravel()]))
+api.release_cache()
+free.append(free_mb())
+assert api.set_device_cache_mb(0, False) == {{False: 4096}}
+np.save({out!r}, np.concatenate(outs))
+np.save({out!r} + ".free.npy", np.array(free))
+"""
+
+
+def test_nothing_survives_a_call_unless_the_caller_opts_in(tmp_path):
+    """"no handles/state survive the call" (ref src/poismf.c:610-617).  By default run_poismf leaves the device's free
+    memory where it found it; after poismf_hip_set_device_cache_mb() the call's arrays stay (~100 MB here) until release_cache();
+    the results are the same bits either way."""
+    out = str(tmp_path / "limit.npy")
+    subprocess.run([sys.executable, "-c", CHILD_LIMIT.format(root=ROOT, out=out)], check=True, cwd=ROOT, timeout=600)
+    res, free = np.load(out), np.load(out + ".free.npy")
+    n = res.size // 3
+    assert np.array_equal(res[:n], res[n:2 * n]) and np.array_equal(res[:n], res[2 * n:])
+    assert abs(int(free[1]) - int(free[0])) <= 8, free            # default: free memory back where it was (MB)
+    assert int(free[0]) - int(free[2]) >= 60, free                # kept: the X arrays of 6e6 nonzeros (~72 MB CSR + CSC) are still there
+    assert abs(int(free[3]) - int(free[0])) <= 8, free            # released
