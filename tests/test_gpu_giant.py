@@ -30,7 +30,7 @@ k, prec = {k}, {prec}
 csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, k, prec, seed=33)
 outs = []
 for _ in range({repeat}):
-    A, B, args = gpu_run(csr, csc, A0, B0, "tncg", 2, k, maxupd={maxupd}, w_mult={w})
+    A, B, args = gpu_run(csr, csc, A0, B0, "tncg", {niter}, k, maxupd={maxupd}, w_mult={w})
     outs.append(np.concatenate([A.ravel(), B.ravel()]).astype(np.float64))
 s = api.Session(csr, csc, A0.shape[0], B0.shape[0], k, prec)
 s.set_factors(A0, B0)
@@ -41,11 +41,11 @@ np.save({out!r}, np.stack(outs))
 """
 
 
-def run_child(tmp_path, tag, env, k=100, prec=False, repeat=1, maxupd=300, w=1.0):
+def run_child(tmp_path, tag, env, k=100, prec=False, repeat=1, maxupd=1500, w=1.0, niter=2):
     out = str(tmp_path / f"{tag}.npy")
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, k=k, prec=prec, repeat=repeat, maxupd=maxupd, w=w)], check=True,
+    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, k=k, prec=prec, repeat=repeat, maxupd=maxupd, w=w, niter=niter)], check=True,
                        env=e, cwd=ROOT, timeout=900, capture_output=True, text=True)
     plan = [l for l in r.stdout.splitlines() if l.startswith("PLAN")][0]
     return np.load(out), plan, r.stderr
@@ -62,12 +62,20 @@ def test_giant_team_rows_vs_oracle_and_repeatable(tmp_path, k, prec, w):
     assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])      # teams form in arrival order; the bits do not care
     csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, k, prec, seed=33)
     l2, _, _ = harness.auto_defaults("tncg", k)
-    args = dict(l2_reg=l2, l1_reg=0.0, w_mult=w, step_size=1e-7, limit_step=True, niter=2, maxupd=300, early_stop=True, reuse_prev=False)
+    args = dict(l2_reg=l2, l1_reg=0.0, w_mult=w, step_size=1e-7, limit_step=True, niter=2, maxupd=1500, early_stop=True, reuse_prev=False)
     Ar, Br = oracle_run(prec, csr, csc, A0, B0, "tncg", args)
     nA = A0.size
     A, B = res[0][:nA].reshape(A0.shape), res[0][nA:].reshape(B0.shape)
     assert not A[-1].any()
-    compare(prec, "tncg", csr, args, A, B, Ar, Br, converged=False)
+    # TNC stops a row when its objective moves by less than ftol = 1e-4 of itself (ref: src/poismf.c:383-391, src/tnc.c:909-915): two summation
+    # orders of the same arithmetic end up to ~1e-4 of a ROW's objective apart, and here three rows of 2500 .. 9000 nonzeros are most of the
+    # total (measured: 5e-5 .. 1.7e-4; the suite's 5e-5 is for rows of at most 1500 nonzeros).  The sharp check of the team's sums is
+    # test_giant_team_sums_match_the_one_workgroup_path below.
+    assert np.isfinite(A).all() and np.isfinite(B).all() and A.min() >= 0 and B.min() >= 0
+    og = harness.poisson_objective(A, B, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
+    orf = harness.poisson_objective(Ar, Br, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
+    print(f"giant teams k={k} w={w}: objective gpu {og:.10g} checker {orf:.10g} rel {abs(og - orf) / abs(orf):.3g}")
+    assert abs(og - orf) <= 5e-4 * abs(orf)
 
 
 def test_giant_team_fp32_is_finite_and_close_to_the_one_workgroup_path(tmp_path):
@@ -86,6 +94,22 @@ def test_giant_team_fp32_is_finite_and_close_to_the_one_workgroup_path(tmp_path)
     assert obj[0] <= obj[1] + 1e-2 * abs(obj[1])
 
 
+def test_giant_team_sums_match_the_one_workgroup_path(tmp_path):
+    """The sharp check: a budget of TWO evaluations per row -- the gradient at the starting point and one line-search trial along it -- on
+    the team path and on the one-workgroup path.  What differs is the order in which 32 x 8 partial sums are added: the factors agree to
+    rounding (measured 1.3e-15; a nonzero dropped or counted twice by the split of a row over the members would show at 1e-4 and above).
+    With a whole truncated-Newton direction (60 evaluations: up to 50 Hessian-vector products by finite differences of step 1.5e-8) the same
+    rounding differences come out at 1e-3 of a row -- in the reference's own two BLAS flavours too -- which is why the
+    tests above hold the converged objective to TNC's own stopping tolerance and no tighter."""
+    for k in (100, 20):
+        team, _, _ = run_child(tmp_path, f"team{k}", {"POISMF_HIP_GIANT_NNZ": "256"}, k=k, maxupd=2, niter=1)
+        one, _, _ = run_child(tmp_path, f"one{k}", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_NO_GIANT_TEAMS": "1"}, k=k, maxupd=2, niter=1)
+        err = H.scaled_err(team[0], one[0])
+        print(f"giant teams vs one workgroup per row, k={k}, two evaluations: scaled error {err:.3g}")
+        assert np.isfinite(team).all() and team[0].any()
+        assert err <= 1e-12
+
+
 def test_giant_team_and_one_workgroup_paths_agree(tmp_path):
     team, _, _ = run_child(tmp_path, "team", {"POISMF_HIP_GIANT_NNZ": "256"})
     one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_NO_GIANT_TEAMS": "1"})
@@ -93,7 +117,7 @@ def test_giant_team_and_one_workgroup_paths_agree(tmp_path):
     l2, _, _ = harness.auto_defaults("tncg", 100)
     nA = A0.size
     o = [harness.poisson_objective(r[0][:nA].reshape(A0.shape), r[0][nA:].reshape(B0.shape), csr, l2, 0.0, 1.0) for r in (team, one)]
-    assert abs(o[0] - o[1]) <= 5e-5 * abs(o[1]), o          # two summation orders of the same fp64 arithmetic (mid-path bound of compare())
+    assert abs(o[0] - o[1]) <= 5e-4 * abs(o[1]), o          # (TNC's own stopping tolerance, see above)
 
 
 def test_a_giant_team_that_gives_up_is_rerun_by_one_workgroup_per_row(tmp_path):
