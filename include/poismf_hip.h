@@ -278,6 +278,17 @@ POISMF_HIP_API int poismf_hip_factors_multiple_decisions(real_t *A, real_t *B, r
                           real_t step_size, size_t niter, size_t maxupd, int method, bool limit_step, bool reuse_mean,
                           unsigned *decisions);
 
+/* The first stage of a half-sweep's column sums, shared between the ranks of a multi-GPU run (the sum itself: ref
+ * src/poismf.c:77-83).  The sum over the FIXED factor of half `which` (A for which = 0, B for which = 1) is cut into
+ * poismf_hip_session_colsum_blocks() blocks whose partial sums depend on the block number alone: a rank computes blocks [b_lo, b_hi) into
+ * the session's partial array (poismf_hip_session_partials: [blocks x k] real_t in device memory), receives the others from its peers
+ * into the same array, and declares it complete (poismf_hip_session_partials_ready): the next half-sweep (or its segment 0) then runs
+ * only the fixed-order second stage.  Bit for bit the unsharded sum. */
+POISMF_HIP_API int poismf_hip_session_colsum_blocks(poismf_hip_session *s, int which);
+POISMF_HIP_API int poismf_hip_session_colsum_partial(poismf_hip_session *s, int which, int b_lo, int b_hi);
+POISMF_HIP_API real_t *poismf_hip_session_partials(poismf_hip_session *s);
+POISMF_HIP_API void poismf_hip_session_partials_ready(poismf_hip_session *s);
+
 /* Nothing survives run_poismf by default: every device array the call allocated is freed before it returns, as the reference frees
  * its scratch (ref src/poismf.c:610-619).  A caller that fits repeatedly on matrices of one shape can OPT IN to keeping released
  * device arrays of 1 MB and more for the next request of the same size on the same device (repeated fits then allocate nothing and

@@ -46,7 +46,8 @@ EXPORTED_SYMBOLS = (
     "poismf_hip_session_set_segments", "poismf_hip_session_segment_rows", "poismf_hip_half_sweep_segment", "poismf_hip_session_plan",
     "poismf_hip_session_launch_profile", "poismf_hip_session_decisions", "poismf_hip_session_decision_stats", "poismf_hip_factors_multiple_decisions",
     "poismf_hip_session_predict", "poismf_hip_session_topn", "poismf_hip_debug_row_eval", "poismf_hip_release_cache",
-    "poismf_hip_set_device_cache_mb",
+    "poismf_hip_set_device_cache_mb", "poismf_hip_session_colsum_blocks", "poismf_hip_session_colsum_partial", "poismf_hip_session_partials",
+    "poismf_hip_session_partials_ready",
 )
 
 
@@ -77,6 +78,14 @@ def load_library(use_float):
     lib.poismf_hip_release_cache.restype = None
     lib.poismf_hip_set_device_cache_mb.argtypes = [sz]
     lib.poismf_hip_set_device_cache_mb.restype = sz
+    lib.poismf_hip_session_colsum_blocks.argtypes = [vp, i]
+    lib.poismf_hip_session_colsum_blocks.restype = i
+    lib.poismf_hip_session_colsum_partial.argtypes = [vp, i, i, i]
+    lib.poismf_hip_session_colsum_partial.restype = i
+    lib.poismf_hip_session_partials.argtypes = [vp]
+    lib.poismf_hip_session_partials.restype = vp
+    lib.poismf_hip_session_partials_ready.argtypes = [vp]
+    lib.poismf_hip_session_partials_ready.restype = None
     lib.predict_multiple.argtypes = [vp, vp, vp, vp, vp, sz, i, i]
     lib.predict_multiple.restype = None
     lib.topN.argtypes = [vp, vp, i, vp, sz, vp, sz, vp, vp, sz, sz, i]
@@ -536,6 +545,22 @@ class Session:
     def factors_dirty(self, which):
         """tell the session that factor `which` (0: B, 1: A) was written through a device pointer obtained earlier"""
         self.lib.poismf_hip_session_factors_dirty(self.h, int(which))
+
+    def colsum_blocks(self, which):
+        """blocks the column sums over the FIXED factor of half `which` are cut into (include/poismf_hip.h)"""
+        return int(self.lib.poismf_hip_session_colsum_blocks(self.h, int(which)))
+
+    def colsum_partial(self, which, b_lo, b_hi):
+        if self.lib.poismf_hip_session_colsum_partial(self.h, int(which), int(b_lo), int(b_hi)):
+            raise RuntimeError("poismf_hip_session_colsum_partial failed")
+
+    def partials_array(self, which):
+        """the session's [blocks x k] partial sums of half `which`, as a __cuda_array_interface__ object aliasing device memory"""
+        nb = self.colsum_blocks(which)
+        return _DevArray(self.lib.poismf_hip_session_partials(self.h), (nb, self.k), "<f4" if self.use_float else "<f8")
+
+    def partials_ready(self):
+        self.lib.poismf_hip_session_partials_ready(self.h)
 
     def profile(self, enable=True):
         self.lib.poismf_hip_session_profile(self.h, int(enable))

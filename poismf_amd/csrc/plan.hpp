@@ -57,8 +57,8 @@ template <class T> struct HalfArgs {
     int reuse_prev, early_stop;
     unsigned* n_unchanged;
     unsigned* queue;                  // != nullptr: rows are handed out dynamically through this counter
-    const unsigned* stop;             // != nullptr (CG / TNCG launches whose rows are dealt out statically): the word the host overwrites when the call is
-                                      // interrupted -- read before every row, as the reference's row loops read should_stop_procedure (ref: src/poismf.c:301, :360)
+    const unsigned* stop;             // != nullptr (CG / TNCG): a word in pinned host memory that the SIGINT handler sets -- read next to every row ticket, as
+                                      // the reference's row loops read should_stop_procedure before every row (ref: src/poismf.c:301, :360)
     unsigned* eval_rows;              // != nullptr (profiling sessions): [local row] += passes over that row's tile
     unsigned* dec_rows;               // != nullptr (profiling sessions): [2 x local row] = the solver's decisions (solvers.hpp, SolveStats)
     unsigned long long* team_buf;     // team launches (several CUs per row, reg_eval.hpp M_ > 1): arrival counters, mailboxes, exchange slots

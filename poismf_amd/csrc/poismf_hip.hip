@@ -119,6 +119,19 @@ __device__ __forceinline__ void solve_row(const HalfArgs<T>& a, EV& ev, const T 
     }
 }
 
+// One ticket from a launch's row queue -- or "past the end" once the call has been interrupted: HalfArgs::stop is a word in pinned host
+// memory that the SIGINT handler itself sets, read (system scope) next to every ticket, as the reference's CG / TNCG row loops read
+// should_stop_procedure before every row (ref: src/poismf.c:301, :360).  The read is issued before the atomic and travels beside it.
+template <int METHOD, class T> __device__ __forceinline__ unsigned take_ticket(const HalfArgs<T>& a)
+{
+    unsigned st = 0u;
+    if constexpr (METHOD != K_PG) {
+        if (a.stop != nullptr) st = __hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned t = atomicAdd(a.queue, 1u);
+    return st != 0u ? 0xffffffffu : t;
+}
+
 // A wavefront (or, NW > 1, a workgroup of NW wavefronts) walks rows blockIdx.x, blockIdx.x + gridDim.x, ... of the
 // nnz-sorted permutation, or pulls them from a device-wide queue.
 //
@@ -145,22 +158,22 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
             if (a.queue != nullptr) {
                 if constexpr (NW > 1) {   // one atomic per workgroup, broadcast through LDS
                     unsigned* slot = ev.ticket_slot();
-                    if (threadIdx.x == 0) *slot = atomicAdd(a.queue, 1u);
+                    if (threadIdx.x == 0) *slot = take_ticket<METHOD>(a);
                     __syncthreads();
                     const unsigned t = uniform(*slot);
                     __syncthreads();
                     return t;
                 }
                 unsigned t = 0;
-                if (ev.lane == 0) t = atomicAdd(a.queue, 1u);
+                if (ev.lane == 0) t = take_ticket<METHOD>(a);
                 return uniform(t);
             }
             unsigned t = r;
             r += gridDim.x;
             if constexpr (METHOD != K_PG) {
-                // (statically dealt rows have no queue head for the host to overwrite: they look at the stop word itself, one L2 read per row
-                // that nothing waits for until the ticket is used, two rows later)
-                if (a.stop != nullptr && __hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) t = 0xffffffffu;
+                // (statically dealt rows: the stop word alone, one read of pinned host memory per row that nothing waits for until the ticket
+                // is used, two rows later)
+                if (a.stop != nullptr && __hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) t = 0xffffffffu;
             }
             return t;
         };
@@ -195,19 +208,19 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
                     // broadcast through the last 16 bytes of the DYNAMIC LDS block (a static __shared__ object
                     // would shift the dynamic base off 16-byte alignment and slow every ds_read_b128 down)
                     unsigned* next_row = ev.ticket_slot();
-                    if (threadIdx.x == 0) *next_row = atomicAdd(a.queue, 1u);
+                    if (threadIdx.x == 0) *next_row = take_ticket<METHOD>(a);
                     __syncthreads();
                     r = uniform(*next_row);
                     __syncthreads();
                 } else {
                     unsigned t = 0;
-                    if (ev.lane == 0) t = atomicAdd(a.queue, 1u);
+                    if (ev.lane == 0) t = take_ticket<METHOD>(a);
                     r = uniform(t);
                 }
             }
             if (r >= a.nrows) break;
             if constexpr (METHOD != K_PG) {
-                if (a.queue == nullptr && a.stop != nullptr && uniform(__hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) break;
+                if (a.queue == nullptr && a.stop != nullptr && uniform(__hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u) break;
             }
             const RowDesc d = desc[r];
             r += gridDim.x;
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_giant_kernel(const HalfAr
         if (threadIdx.x == 0) {
             unsigned tk = END;
             if (ev.member == 0) {
-                tk = atomicAdd(a.queue, 1u);
+                tk = take_ticket<METHOD>(a);
                 if (tk >= a.nrows || __hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) tk = END;
                 gt_store(mail + (rowno & 1u), ((unsigned long long)rowno << 32) | tk);
             } else {
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
     auto next_ticket = [&](unsigned rowno_next) -> unsigned {     // (call with all threads)
         if (ev.member == 0) {
             if (threadIdx.x == 0) {
-                box[0] = atomicAdd(a.queue, 1u);
+                box[0] = take_ticket<METHOD>(a);
                 gran_store(mail + (rowno_next & 1u), ((unsigned long long)rowno_next << 32) | (box[0] < a.nrows ? box[0] : END));
             }
         } else if (threadIdx.x == 0) {

@@ -23,6 +23,9 @@
 
 #include "plan.hpp"
 
+// the device-visible twin of the interrupt flag (pinned host memory; see on_sigint below): one word, allocated on first use, never freed
+static volatile unsigned* g_stop_word = nullptr;
+
 static int launch_one(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
 {
     return method == POISMF_PG ? pmf_launch_one_tu3(method, o, a) : method == POISMF_CG ? pmf_launch_one_tu2(method, o, a) :
@@ -82,16 +85,20 @@ template <class T> __global__ __launch_bounds__(256) void repad_kernel(const T* 
 // through LDS in wave order, so the 256-way partial written by the block is bit-reproducible.
 constexpr int COLSUM_BLOCK_WAVES = 8;
 template <class T, int NC>
-__global__ __launch_bounds__(WAVE* COLSUM_BLOCK_WAVES) void colsum_partial_kernel(const T* M, size_t n, int k, T* partial)
+__global__ __launch_bounds__(WAVE* COLSUM_BLOCK_WAVES) void colsum_partial_kernel(const T* M, size_t n, int k, T* partial, unsigned block0, unsigned nblocks)
 {
+    // (block0 / nblocks: this launch computes blocks [block0, block0 + gridDim.x) of the nblocks the whole sum is cut into -- a block's
+    // partial sum depends on nblocks and on its own number alone, so ANY subset of blocks, computed anywhere, gives the same bits: what lets
+    // the ranks of a multi-GPU run share the first stage, poismf_hip_session_colsum_partial)
     __shared__ T part[COLSUM_BLOCK_WAVES][NC * WAVE];
     const int lane = lane_id();
     const int w = (int)(threadIdx.x / WAVE);
     T acc[NC];
     PMF_EW acc[i] = (T)0;
     // four rows in flight per wave (the loop is latency-bound: one 200-byte row per trip); added in row order as before
-    const size_t stride = (size_t)gridDim.x * COLSUM_BLOCK_WAVES;
-    size_t r = (size_t)blockIdx.x * COLSUM_BLOCK_WAVES + w;
+    const unsigned bid = blockIdx.x + block0;
+    const size_t stride = (size_t)nblocks * COLSUM_BLOCK_WAVES;
+    size_t r = (size_t)bid * COLSUM_BLOCK_WAVES + w;
     for (; r + 3 * stride < n; r += 4 * stride) {
         T v[4][NC];
 #pragma unroll
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(WAVE* COLSUM_BLOCK_WAVES) void colsum_partial_kerne
             if (c < k) {
                 T s = part[0][c];
                 for (int q = 1; q < COLSUM_BLOCK_WAVES; q++) s += part[q][c];
-                partial[(size_t)blockIdx.x * k + c] = s;
+                partial[(size_t)bid * k + c] = s;
             }
         }
     }
@@ -242,6 +249,7 @@ struct poismf_hip_session {
     size_t team_backup_elems = 0;
     bool team_launched = false;             // since the words were last read
     int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
+    bool partials_given = false;      // d_partial already holds every block's partial sum for the NEXT half-sweep (poismf_hip_session_partials_ready)
     bool profiling = false;
     std::vector<ProfRec> prof;
     std::vector<LaunchRec> lprof;
@@ -538,17 +546,45 @@ namespace {
 
 // column-sum kernels: elements per lane in the plain lane <-> element layout
 int nc_for_k(size_t k) { return k <= 64 ? 1 : (k <= 128 ? 2 : (k <= 256 ? 4 : (k <= 512 ? 8 : 0))); }
+inline int colsum_blocks_for(const poismf_hip_session* s, size_t n)
+{
+    return (int)std::min<size_t>((size_t)s->colsum_waves, std::max<size_t>((n + COLSUM_BLOCK_WAVES - 1) / COLSUM_BLOCK_WAVES, 1));
+}
+template <int NC> int launch_colsum_partial(poismf_hip_session* s, const real_t* M, size_t n, int b_lo, int b_hi)
+{
+    const int nw = colsum_blocks_for(s, n);
+    if (b_lo < 0 || b_hi > nw || b_lo > b_hi) return 1;
+    if (b_hi > b_lo)
+        hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(b_hi - b_lo), dim3(WAVE * COLSUM_BLOCK_WAVES), 0, s->stream, M, n, (int)s->k,
+                           s->d_partial, (unsigned)b_lo, (unsigned)nw);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 template <int NC> int launch_colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
 {
-    const int nw = (int)std::min<size_t>((size_t)s->colsum_waves, std::max<size_t>((n + COLSUM_BLOCK_WAVES - 1) / COLSUM_BLOCK_WAVES, 1));
-    hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(nw), dim3(WAVE * COLSUM_BLOCK_WAVES), 0, s->stream, M, n, (int)s->k,
-                       s->d_partial);
+    const int nw = colsum_blocks_for(s, n);
+    // first stage: all blocks here, or only [b_lo, b_hi) (the others are the peers' and have been put into d_partial by the caller), or none
+    int b_lo = 0, b_hi = nw;
+    if (s->partials_given) { b_lo = b_hi = 0; s->partials_given = false; }
+    if (b_hi > b_lo)
+        hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(b_hi - b_lo), dim3(WAVE * COLSUM_BLOCK_WAVES), 0, s->stream, M, n, (int)s->k,
+                           s->d_partial, (unsigned)b_lo, (unsigned)nw);
     hipLaunchKernelGGL((colsum_final_kernel<real_t, NC>), dim3(1), dim3(WAVE * COLSUM_FINAL_WAVES), 0, s->stream, s->d_partial, nw, (int)s->k, l1,
                        scale, nscale, s->d_bsum);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+int colsum_partial(poismf_hip_session* s, const real_t* M, size_t n, int b_lo, int b_hi)
+{
+    switch (nc_for_k(s->k)) {
+        case 1: return launch_colsum_partial<1>(s, M, n, b_lo, b_hi);
+        case 2: return launch_colsum_partial<2>(s, M, n, b_lo, b_hi);
+        case 4: return launch_colsum_partial<4>(s, M, n, b_lo, b_hi);
+        case 8: return launch_colsum_partial<8>(s, M, n, b_lo, b_hi);
+    }
+    return 1;
+}
 int colsum(poismf_hip_session* s, const real_t* M, size_t n, real_t l1, real_t scale, int nscale)
 {
     switch (nc_for_k(s->k)) {
@@ -644,7 +680,7 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     if (pmf_alloc(&s->d_bsum, k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 24), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs; [+16] the stop word of the statically dealt CG / TNCG launches, [+17] a spare word)
+    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 24), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs)
     if (pmf_alloc(&s->d_arrive, sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_team_err, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
@@ -788,6 +824,20 @@ real_t* poismf_hip_session_A(poismf_hip_session* s) { s->padded_fresh[1] = false
 real_t* poismf_hip_session_B(poismf_hip_session* s) { s->padded_fresh[0] = false; return s->dB; }
 // ... and whoever keeps such a pointer says so after every later write (which = 0: B was written, 1: A)
 void poismf_hip_session_factors_dirty(poismf_hip_session* s, int which) { s->padded_fresh[which ? 1 : 0] = false; }
+
+// ---- the first stage of the column sums, shared between the ranks of a multi-GPU run (ref: src/poismf.c:77-83) -----------------
+// The sum over the fixed factor of half `which` (A for the B half, B for the A half) is cut into poismf_hip_session_colsum_blocks() blocks
+// whose partial sums do not depend on who computes them.  A rank computes blocks [b_lo, b_hi) into the session's partial array
+// (poismf_hip_session_partials: [blocks x k] real_t, device memory), receives the other blocks from its peers into the same array, and says so
+// (poismf_hip_session_partials_ready): the next half-sweep then runs the fixed-order second stage only.  Same bits as the unsharded sum.
+int poismf_hip_session_colsum_blocks(poismf_hip_session* s, int which) { return colsum_blocks_for(s, which ? s->dimB : s->dimA); }
+int poismf_hip_session_colsum_partial(poismf_hip_session* s, int which, int b_lo, int b_hi)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    return colsum_partial(s, which ? s->dB : s->dA, which ? s->dimB : s->dimA, b_lo, b_hi);
+}
+real_t* poismf_hip_session_partials(poismf_hip_session* s) { return s->d_partial; }
+void poismf_hip_session_partials_ready(poismf_hip_session* s) { s->partials_given = true; }
 void* poismf_hip_session_stream(poismf_hip_session* s) { return (void*)s->stream; }
 size_t poismf_hip_session_nnz(poismf_hip_session* s, int which) { return s->half[which ? 1 : 0].nnz; }
 
@@ -1163,7 +1213,6 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const int pg_lane_rows = getenv("POISMF_HIP_PG_LANE_ROWS") ? atoi(getenv("POISMF_HIP_PG_LANE_ROWS")) : 0;
     const bool pg_queue = is_pg && pg_lane_rows == 1 && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
     if (dynamic || pg_queue) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
-    if (!is_pg) HIP_TRY(hipMemsetAsync(s->d_queue + MAX_LAUNCHES + 16, 0, sizeof(unsigned), s->stream));   // the stop word of the statically dealt launches
     // the few workgroup-per-row launches of the power-law tail occupy a few dozen CUs for a long time: run them on a
     // second stream beside the other bins (fork after the column sums, join before anything reads the result)
     // Several launches per half: they also alternate between the two streams (each to the one with less work queued so
@@ -1209,7 +1258,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             if (char* sp = strstr(lname, " rows=")) *sp = 0;
         }
         a.queue = (dynamic || (pg_queue && L.lane_L > 0 && L.nw > 1)) ? s->d_queue + launch_no : nullptr;
-        a.stop = is_pg ? nullptr : s->d_queue + MAX_LAUNCHES + 16;   // (a word of the array the interrupt watcher overwrites: zeroed below)
+        a.stop = is_pg ? nullptr : (const unsigned*)g_stop_word;   // (pinned host memory, portable: the same address on every device)
         launch_no++;
         a.perm_begin = L.begin;
         a.nrows = L.count;
@@ -1478,9 +1527,34 @@ int poismf_hip_half_sweep_segment(poismf_hip_session* s, int which, const poismf
 static volatile sig_atomic_t g_should_stop = 0;
 static bool g_handle_locked = false;
 static std::mutex g_handle_mutex;
+// The interrupt reaches the row loops of CG / TNCG within a row (ref: src/poismf.c:301, :360: the reference's row loops test
+// should_stop_procedure before every row and skip the rest).  Rounds 1-4 looked at the flag between half-sweeps only: up to one half (config
+// C5: 260 ms) of latency.  The flag now has a twin in PINNED HOST MEMORY that the device reads directly (HalfArgs::stop, system-scope loads
+// next to every row ticket): the handler's own store is all it takes -- no thread, no copy, no kernel that would have to find a free CU
+// behind the very workgroups it is meant to stop (a first version overwrote the device-side queue heads by hipMemsetAsync / hipMemcpyAsync:
+// 14 .. 290 ms, depending on what the chip was running).  PG has no poll (neither has the reference's pg_iteration, quirk Q8).
 static void on_sigint(int)
 {
     g_should_stop = 1;  // the reference also prints here; fprintf is not async-signal-safe, so run_poismf reports it
+    volatile unsigned* w = g_stop_word;
+    if (w != nullptr) *w = 1u;
+}
+// (g_handle_mutex held, or single-threaded) the device-visible twin of the flag; nullptr if it cannot be had (the flag is then polled
+// between half-sweeps only, as before)
+static const unsigned* stop_word_for_device()
+{
+    static bool tried = false;
+    static const bool off = getenv("POISMF_HIP_NO_ROW_INTERRUPT") != nullptr;   // testing knob
+    if (off) return nullptr;
+    if (!tried) {
+        tried = true;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p != nullptr) {
+            *(volatile unsigned*)p = g_should_stop ? 1u : 0u;
+            g_stop_word = (volatile unsigned*)p;
+        } else (void)hipGetLastError();
+    }
+    return (const unsigned*)g_stop_word;
 }
 
 // SIGINT plumbing of one call (ref: src/poismf.c:444-455, :618-630): the first call in the process to get here installs
@@ -1497,6 +1571,8 @@ struct SigintScope {
             g_handle_locked = true;
             has_lock = true;
             g_should_stop = 0;
+            (void)stop_word_for_device();
+            if (g_stop_word != nullptr) *g_stop_word = 0u;
             old_handler = signal(SIGINT, on_sigint);
         }
     }
@@ -1510,92 +1586,10 @@ struct SigintScope {
             signal(SIGINT, old_handler);
             g_handle_locked = false;
             g_should_stop = 0;
+            if (g_stop_word != nullptr) *g_stop_word = 0u;
         }
         if (stopped && !handle_interrupt) raise(SIGINT);
         return ret_code;
-    }
-};
-
-// ---- the interrupt reaches the row loops of CG / TNCG within a row (ref: src/poismf.c:301, :360: the reference's row loops test
-// should_stop_procedure before every row and skip the rest) -----------------------------------------------------------------------
-// Rounds 1-4 looked at the flag between half-sweeps only: up to one half (config C5: 260 ms) of latency.  CG and TNCG hand their rows
-// out through device-side queue heads (one returning atomic per row, HalfArgs::queue).  While such a run is active a host thread
-// looks at the flag every 200 us; once it is set it overwrites the session's queue heads with 0x80808080 -- every later ticket is
-// past the end of its launch, so each workgroup finishes the row it is on and leaves, exactly as the reference's threads do; rows
-// not reached keep their values (as in the reference) -- and keeps doing so (a half that had not been launched yet resets its heads
-// first) until the run ends.  Nothing is added to the kernels: the poll is the ticket they take anyway.  PG has no queue and no
-// poll (neither has the reference's pg_iteration, quirk Q8).
-struct StopPoison {   // per device, created once per process: a side stream and a pinned pattern of "past the end" queue heads
-    hipStream_t side = nullptr;
-    unsigned* pattern = nullptr;
-    bool tried = false;
-};
-inline StopPoison* stop_poison(int device)
-{
-    static StopPoison per_dev[64];
-    static std::mutex mu;
-    StopPoison& sp = per_dev[device >= 0 && device < 64 ? device : 0];
-    std::lock_guard<std::mutex> lk(mu);
-    if (!sp.tried) {
-        sp.tried = true;
-        if (hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&sp.side, hipStreamNonBlocking) == hipSuccess &&
-            hipHostMalloc((void**)&sp.pattern, sizeof(unsigned) * (MAX_LAUNCHES + 24), hipHostMallocDefault) == hipSuccess) {
-            for (int i = 0; i < MAX_LAUNCHES + 24; i++) sp.pattern[i] = 0x80808080u;
-        } else {
-            sp.side = nullptr; sp.pattern = nullptr;
-            (void)hipGetLastError();
-        }
-    }
-    return &sp;
-}
-struct StopWatch {
-    std::vector<poismf_hip_session*> ss;
-    std::vector<StopPoison*> sp;
-    std::thread th;
-    std::atomic<bool> quit{false};
-    explicit StopWatch(std::vector<poismf_hip_session*> sessions, int method) : ss(std::move(sessions))
-    {
-        if (method == POISMF_PG || getenv("POISMF_HIP_NO_ROW_INTERRUPT") != nullptr) return;
-        // (the side stream and the pinned pattern exist before the run starts: the watcher's first HIP call must not be a 200 ms one.
-        // The pattern travels by a copy from pinned memory -- the DMA engine -- not by a fill kernel, which would wait for a free CU
-        // behind the very workgroups it is meant to stop)
-        for (poismf_hip_session* s1 : ss) sp.push_back(s1 != nullptr ? stop_poison(s1->device) : nullptr);
-        for (poismf_hip_session* s1 : ss) if (s1 != nullptr) (void)hipSetDevice(s1->device);   // (back on the caller's device: one session per calling thread)
-        th = std::thread([this] {
-            // (this thread's first copy on the side stream costs ~200 ms of one-time set-up in the runtime: spent now, under the first
-            // half-sweep, into the spare word [MAX_LAUNCHES + 17] that nothing reads -- not when the signal arrives)
-            for (size_t i = 0; i < ss.size(); i++) {
-                if (ss[i] == nullptr || ss[i]->d_queue == nullptr || sp[i] == nullptr || sp[i]->side == nullptr) continue;
-                if (hipSetDevice(ss[i]->device) != hipSuccess) continue;
-                (void)hipMemcpyAsync(ss[i]->d_queue + MAX_LAUNCHES + 17, sp[i]->pattern, sizeof(unsigned), hipMemcpyHostToDevice, sp[i]->side);
-                (void)hipStreamSynchronize(sp[i]->side);
-            }
-            while (!quit.load(std::memory_order_acquire)) {
-                if (g_should_stop) {
-                    for (size_t i = 0; i < ss.size(); i++) {
-                        if (ss[i] == nullptr || ss[i]->d_queue == nullptr || sp[i] == nullptr || sp[i]->side == nullptr) continue;
-                        if (hipSetDevice(ss[i]->device) != hipSuccess) continue;
-                        (void)hipMemcpyAsync(ss[i]->d_queue, sp[i]->pattern, sizeof(unsigned) * (MAX_LAUNCHES + 17), hipMemcpyHostToDevice, sp[i]->side);
-                    }
-                    struct timespec ts = { 0, 1000000 };   // again in 1 ms: a half launched meanwhile has reset its heads
-                    nanosleep(&ts, nullptr);
-                } else {
-                    struct timespec ts = { 0, 200000 };
-                    nanosleep(&ts, nullptr);
-                }
-            }
-            for (size_t i = 0; i < ss.size(); i++) {
-                if (ss[i] == nullptr || sp[i] == nullptr || sp[i]->side == nullptr) continue;
-                (void)hipSetDevice(ss[i]->device);
-                (void)hipStreamSynchronize(sp[i]->side);
-            }
-            (void)hipGetLastError();
-        });
-    }
-    ~StopWatch()
-    {
-        quit.store(true, std::memory_order_release);
-        if (th.joinable()) th.join();
     }
 };
 
@@ -1609,7 +1603,6 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
     real_t step_size = p.step_size;
     const bool tn_stop = (method == POISMF_TNCG) && p.early_stop;
     bool stopped_earlyA = false, stopped_earlyB = false;
-    StopWatch watch({ s }, method);
     for (size_t it = 0; it < numiter; it++) {
         if (g_should_stop) break;
         // quirk Q6: the divisor uses the step before halving and is reused by the A half
@@ -1812,7 +1805,6 @@ int run_poismf_multi(const std::vector<int>& devices, real_t* A, real_t* Xr, spa
         pmf_last_hip_error() = hipSuccess;
         if (setup(d)) R.fail(d);
         R.bar.arrive();
-        StopWatch watch({ R.ss[d] }, method);   // (an interrupt empties this device's row queues: the halves already enqueued end within a row)
         real_t step_size = p.step_size;
         bool stoppedA = false, stoppedB = false;
         unsigned h = 0;

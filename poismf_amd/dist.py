@@ -3,8 +3,13 @@
 Rows of the factor being updated are independent given the full opposing factor, so each rank owns a
 contiguous range of A rows (a CSR slice) and a contiguous range of B rows (a CSC slice); both factors are
 replicated.  After each half-sweep the just-updated shard travels to every other replica (RCCL over xGMI on
-the GPU, gloo in the CPU tests); the k-length column sums are recomputed locally from the replica, which is
-deterministic and needs no further collective.
+the GPU, gloo in the CPU tests).  The k-length column sums of the fixed factor: every rank needs the same bits, and
+a k-vector all-reduce over partial sums of row SHARDS would make them depend on the sharding; instead the sum is cut
+into fixed blocks whose partial sums depend on the block number alone (include/poismf_hip.h,
+poismf_hip_session_colsum_partial), each rank computes its 1/W of the blocks over the whole replica, the
+[blocks x k] partials are all-gathered (100-400 KB) and every rank runs the fixed-order second stage: the unsharded
+sum bit for bit, with the first stage's 1 / W per rank instead of all of it (round 4 recomputed the whole sum on
+every rank: at C4 on 8 GPUs 50 us of a 650 us half).  Factors below SHARD_COLSUM_MIN_ROWS rows are summed locally.
 
 The exchange is written for xGMI's full mesh, not for a ring: every rank sends its rows DIRECTLY to each of its
 W - 1 peers and receives theirs straight into place in its replica -- one grouped launch of 2 (W - 1) point-to-point
@@ -119,6 +124,9 @@ def exchange_shards(full, parts, rank, group=None):
             w.wait()
 
 
+SHARD_COLSUM_MIN_ROWS = int(os.environ.get("POISMF_SHARD_COLSUM_MIN_ROWS", "262144"))   # (a 1e5-row factor sums in 5 us: not worth a collective)
+
+
 class HipBackend:
     """The HIP session of this rank; factors are exposed as torch tensors aliasing the session's HBM."""
 
@@ -167,6 +175,23 @@ class HipBackend:
     def factors_dirty(self, which):
         self.sess.factors_dirty(which)
 
+    # -- the first stage of the column sums, shared between the ranks (module docstring) --
+    def colsum_rows(self, which):
+        """rows of the FIXED factor of half `which` (A for the B half, B for the A half)"""
+        return self.sess.dimB if which else self.sess.dimA
+
+    def colsum_blocks(self, which):
+        return self.sess.colsum_blocks(which)
+
+    def colsum_partial(self, which, b_lo, b_hi):
+        self.sess.colsum_partial(which, b_lo, b_hi)
+
+    def partials(self, which):
+        return torch.as_tensor(self.sess.partials_array(which), device=self._A.device)
+
+    def partials_ready(self):
+        self.sess.partials_ready()
+
     def close(self):
         self.sess.close()
 
@@ -193,6 +218,20 @@ class ShardedAlternation:
         parts = [segment_of(r, j, nseg) for r in self.ranges[which]]
         exchange_shards(self.be.factor(which), parts, self.rank, self.group)
 
+    def _shared_colsum(self, which, ctx):
+        """Each rank computes its share of the blocks of the fixed factor's column sums, the partials are all-gathered (in the
+        session's stream order: the half-sweep that follows reads them), and the backend is told they are complete."""
+        be = self.be
+        if not (self.multi and hasattr(be, "colsum_partial") and be.colsum_rows(which) >= SHARD_COLSUM_MIN_ROWS):
+            return
+        world = dist.get_world_size(self.group)
+        nb = be.colsum_blocks(which)
+        parts = equal_ranges(nb, world)
+        be.colsum_partial(which, *parts[self.rank])
+        with (ctx() if ctx is not None else contextlib.nullcontext()):
+            exchange_shards(be.partials(which), parts, self.rank, self.group)
+        be.partials_ready()
+
     def _half(self, which, cnst_div):
         if self.method == "tncg" and self.stopped[which]:
             return
@@ -200,6 +239,7 @@ class ShardedAlternation:
         ctx = getattr(self.be, "stream_context", None)
         comm = getattr(self.be, "comm_stream", None)
         n = 0
+        self._shared_colsum(which, ctx)
         if nseg == 1:
             n = self.be.half_sweep(which, self.step, cnst_div, self.early_stop)
             with (ctx() if ctx is not None else contextlib.nullcontext()):

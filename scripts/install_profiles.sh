@@ -1,12 +1,13 @@
 #!/bin/bash
-# usage: scripts/install_profiles.sh <tag> [round dir, default r04]: copy what scripts/profile_round.sh left in
+# usage: scripts/install_profiles.sh <tag> [round dir, default r05]: copy what scripts/profile_round.sh left in
 # gpurun_out/<tag>/ into profiles/<round>/ (tracked) and refresh profiles/hbm_traffic.json.  Only the files this script writes are
 # replaced: whatever else lives in the round's directory (probe outputs, run_config records, kernel_resource_usage.txt) stays.
 set -e
 cd "$(dirname "$0")/.."
-SRC=gpurun_out/$1; DST=profiles/${2:-r04}
+SRC=gpurun_out/$1; DST=profiles/${2:-r05}
 mkdir -p $DST/pmc
 cp $SRC/bench_line.json $DST/bench_line.json
+[ -f $SRC/bench_full.json ] && cp $SRC/bench_full.json $DST/bench_full.json
 for n in pg10 pg1 cg64 cg32 tncg32 c5; do
   [ -f $SRC/kt_$n/kt_kernel_stats.csv ] || continue
   cp $SRC/kt_$n/kt_kernel_stats.csv $DST/kt_${n}_kernel_stats.csv

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, through gpurun):  scripts/profile_round.sh <tag> [round name stamped into hbm_traffic.json, default r04]
+# usage (on the GPU box, through gpurun):  scripts/profile_round.sh <tag> [round name stamped into hbm_traffic.json, default r05]
 # Produces gpurun_out/<tag>/: the default bench line, rocprofv3 --kernel-trace --stats of the workloads behind it (PG fp32
 # with maxupd 10 and 1, CG fp64, CG fp32, TNCG fp32, all on the 1M x 100K / 1e8-nnz matrix) and PMC passes (FETCH_SIZE and WRITE_SIZE separately,
 # TCC hit / miss, SQ issue / wait counters) of the same commands.  scripts/install_profiles.sh copies the summaries to profiles/.
@@ -9,13 +9,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 # 1. the default command as the driver runs it
-$B > $OUT/bench_default.log 2>&1; grep '^{"metric"' $OUT/bench_default.log | tail -1 > $OUT/bench_line.json
+$B > $OUT/bench_default.log 2>&1; grep '^{"metric"' $OUT/bench_default.log | tail -1 > $OUT/bench_line.json; cp $R/bench_full.json $OUT/bench_full.json
 # 2. one workload per command: kernel trace, then counters.  Each run makes warmup + steps timed sweeps and the same again
 #    with the session's own event timing on (the pass `roofline` is computed from): 2 x (1 + STEPS) sweeps per run.
 run() {   # name, sweeps flags..., bench flags
   name=$1; shift
   rocprofv3 --kernel-trace --stats -d $OUT/kt_$name -o kt --output-format csv -- $B --no-cpu --no-extra "$@" > $OUT/kt_$name.log 2>&1
-  grep '^{"metric"' $OUT/kt_$name.log | tail -1 > $OUT/kt_${name}_bench_line.json
+  cp $R/bench_full.json $OUT/kt_${name}_bench_line.json   # (the full object of that run: bench.py's printed line is the compact one)
   rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f_$name -o pmc --output-format csv -- $B --no-cpu --no-extra "$@" > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w_$name -o pmc --output-format csv -- $B --no-cpu --no-extra "$@" > /dev/null 2>&1
   # (L2 hit / miss: the headline workload only -- the whole round has to fit one gpurun call)
@@ -32,7 +32,7 @@ summaries() {
   find $OUT -name "*counter_collection.csv" -delete
   find $OUT -name "*kernel_trace.csv" -delete
   find $OUT -name "*agent_info.csv" -delete
-  python3 $R/scripts/traffic_from_pmc.py $OUT ${2:-r04} > $OUT/hbm_traffic.json
+  python3 $R/scripts/traffic_from_pmc.py $OUT ${2:-r05} > $OUT/hbm_traffic.json
 }
 summaries "$@"
 # config C5 (its own matrix, k = 100, tncg fp64) through scripts/run_config.py: 2 warm-up + 3 timed sweeps, no oracle sample.  Last, and

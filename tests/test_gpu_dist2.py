@@ -18,11 +18,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("method,prec,early", [("pg", "f32", False), ("cg", "f64", False), ("cg", "f32", False),
-                                               ("tncg", "f64", True)])
-def test_two_processes_reproduce_the_single_process_result(method, prec, early, tmp_path):
+@pytest.mark.parametrize("method,prec,early,shared_colsum", [("pg", "f32", False, True), ("cg", "f64", False, True), ("cg", "f32", False, True),
+                                                             ("tncg", "f64", True, True), ("pg", "f32", False, False)])
+def test_two_processes_reproduce_the_single_process_result(method, prec, early, shared_colsum, tmp_path):
+    """shared_colsum: the first stage of the column sums cut between the ranks and its partials exchanged (poismf_amd/dist.py,
+    _shared_colsum; forced here for factors of any size) -- the same bits as every rank summing the whole replica (the other case)."""
     out = str(tmp_path / "ranks.npz")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               POISMF_SHARD_COLSUM_MIN_ROWS="1" if shared_colsum else str(10 ** 9))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "tests", "dist2_worker.py"), out, method, prec] + (["early"] if early else [])
     subprocess.run(cmd, check=True, env=env, cwd=ROOT, timeout=900)
