@@ -208,13 +208,18 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
             // reduction (lane_eval.hpp, TX_): 39 KB of LDS for up to 48 nonzeros (four rows per CU), 52 KB up to 64 (three).
             // POISMF_HIP_NO_TX=1: the reduction (rounds 3-4)
             static const bool no_tx = getenv("POISMF_HIP_NO_TX") != nullptr;
+            static const unsigned tx_max = getenv("POISMF_HIP_TX_MAX") ? (unsigned)atoi(getenv("POISMF_HIP_TX_MAX")) : 64u;   // tuning knob: 48 = the image for rows of at most 48 nonzeros only
             if (cls <= 48 && !no_tx) return { 1, 0, 0, 1, 0, 0, 48 };
-            if (cls <= 64 && !no_tx) return { 1, 0, 0, 1, 0, 0, 64 };
+            if (cls <= 64 && cls <= tx_max && !no_tx) return { 1, 0, 0, 1, 0, 0, 64 };
             if (cls <= 64) return { 1, 0, 0, 1, 0 };
             // (two such rows per CU: config C5's user rows of 65 .. ~95 nonzeros leave the streamed path; tuning knob
             // POISMF_HIP_K100_LANE_MAX=<64|128>)
             static const unsigned k100_max = getenv("POISMF_HIP_K100_LANE_MAX") ? (unsigned)atoi(getenv("POISMF_HIP_K100_LANE_MAX")) : 384u;
-            if (cls <= 128 && cls <= k100_max) return { 1, 0, 1, 1, 0 };
+            // 65 .. 128 nonzeros: one register set + one LDS set on one wave takes 63 KB of LDS -- two rows per CU, two of its four SIMDs idle;
+            // two waves of one register set each (no LDS set) keep all four busy on the same two rows (POISMF_HIP_K100_MID=1: the one-wave
+            // instance of rounds 4-5a)
+            static const int k100_mid = getenv("POISMF_HIP_K100_MID") ? atoi(getenv("POISMF_HIP_K100_MID")) : 2;
+            if (cls <= 128 && cls <= k100_max) return k100_mid == 2 ? LaneShape{ 1, 0, 0, 2, 0 } : LaneShape{ 1, 0, 1, 1, 0 };
             // 129 .. 384 nonzeros (round 5): four waves of one register set + a partial LDS set of 32 nonzeros each, one row per CU: config
             // C5's item rows of this length stay on chip for all of TNC's ~70 evaluations instead of re-streaming 800 bytes per nonzero
             // for each of them (153 x the algorithmic traffic in round 4's streamed launch)

@@ -790,6 +790,7 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
             switch (key) {
                 case 10010: return launch_lane<METHOD, 50, 1, 0, 0, 1>(stream, a, grid_mult);
                 case 10110: return launch_lane<METHOD, 50, 1, 0, 1, 1>(stream, a, grid_mult);
+                case 10020: return launch_lane<METHOD, 50, 1, 0, 0, 2>(stream, a, grid_mult);
                 case 110040: if (lp == 32) return launch_lane<METHOD, 50, 1, 0, 0, 4, false, false, 32>(stream, a, grid_mult); break;
             }
         }

@@ -223,7 +223,7 @@ K100_LENGTHS = [1, 16, 17, 40, 47, 48, 49, 60, 63, 64, 65, 100, 127, 128, 129, 1
 def test_k100_fp64_lane_instances_on_both_sides_of_every_hand_over(method, w):
     """k = 100 fp64 (config C5's shape) -- the lane engine's instances of round 5 against the oracle, rows on either side of every
     hand-over: <= 48 / <= 64 nonzeros with the gradient accumulated from the row-major LDS image (lane_eval.hpp, TX_ = 48 / 64; the tile
-    lives in LDS only), 65 .. 128 one register set + one LDS set, 129 .. 384 four waves of one register set + a partial LDS set of 32
+    lives in LDS only), 65 .. 128 two waves of one register set each (POISMF_HIP_K100_MID=1: one wave, one register + one LDS set), 129 .. 384 four waves of one register set + a partial LDS set of 32
     nonzeros (one row per CU), above that the streamed engine.  With weights the per-row constant term takes the column sums of the
     tile from the same image.  And the same rows three times give the same bits."""
     k = 100
