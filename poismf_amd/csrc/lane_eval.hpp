@@ -233,6 +233,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr int PART_BYTES = LP_ > 0 ? (LP_ * W * 16 + 1023) / 1024 * 1024 : 0;
     static constexpr int AVEC_BYTES = (KP * (int)sizeof(T) + 15) / 16 * 16;
     static constexpr int WAVE_BYTES = NBUF * STAGE_BYTES + NCH * PART_BYTES + (ALIAS ? 0 : RED_BYTES) + TX_BYTES + AVEC_BYTES;
+    static_assert(!ALIAS || RED_BYTES <= NBUF * STAGE_BYTES, "the reduction's scratch aliases the staging buffer(s): it must fit them (PMF_LANE_XPOSE = 1 on a SMALL instance does not)");
     // cross-wave scratch (NW > 1): two alternating sets of { NW x 64 NC doubles, NW scalars }
     static constexpr int XW_BYTES = NW_ > 1 ? NW_ * WAVE * NC * (int)sizeof(T) + 16 * ((NW_ * 8 + 15) / 16) : 0;
     static constexpr int SMEM_BYTES = NW * WAVE_BYTES + 2 * XW_BYTES + 16;

@@ -183,7 +183,9 @@ inline TeamShape team_shape_for(unsigned max_nnz)
 // shortest rows) and of 13 slots in floats (k = 49..52).  Lane sets (64 nonzeros each) per wave -- in architectural registers,
 // in accumulator registers, in LDS -- and waves per row for rows of a length class; waves 0 = not a row of this engine.
 // A function of the class bound (and the solver) alone, so a row's arithmetic does not depend on its shard.
-struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; int tx = 0; };   // tx: rows of the LDS image the gradient is accumulated from (lane_eval.hpp, TX_)   // small: a few KB of LDS per wave, two waves per SIMD; lp: nonzeros of a partial LDS set
+// lv / la / ll: lane sets per wave in architectural registers / accumulator registers / LDS; waves: per row; small: the two-waves-per-SIMD flavour (a few KB
+// of LDS per wave); lp: nonzeros of a further, partial LDS set; tx: rows of the LDS image the gradient is accumulated from (lane_eval.hpp, TX_)
+struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; int tx = 0; };
 #ifndef PMF_LANE_A2
 #define PMF_LANE_A2 0   // doubles, rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
                         // (measured, C3 A half, CG fp64: 22.3 ms against 20.0 -- the barrier per evaluation and the second copy of the
@@ -198,6 +200,10 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
         if (method == POISMF_PG) return { 0, 0, 0, 0, 0 };
         if (s_load == 25) {          // a set is 100 registers / 25.6 KB of LDS
             if (cls <= 64) return { 1, 0, 0, 1, 1 };
+            // 65 .. 96 nonzeros (round 5; a third of config C3's user rows): one register set + a PARTIAL LDS set of 32 -- 18.8 KB of LDS per row
+            // instead of the 36 KB of a full LDS set: eight rows per CU, two waves per SIMD (POISMF_HIP_K50_P32=0: off)
+            static const bool k50_p32 = getenv("POISMF_HIP_K50_P32") == nullptr || atoi(getenv("POISMF_HIP_K50_P32")) != 0;
+            if (cls <= 96 && k50_p32 && method != POISMF_TNCG) return { 1, 0, 0, 1, 1, 32 };
             if (cls <= 128) return PMF_LANE_A2 ? LaneShape{ 1, 0, 0, 2, 1 } : LaneShape{ 1, 0, 1, 1, 0 };
             if (cls <= 256) return { 1, 2, 1, 1, 0 };
             if (cls <= 512) return { 1, 2, 1, 2, 0 };

@@ -783,6 +783,9 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
                 case 12120: return launch_lane<METHOD, 25, 1, 2, 1, 2>(stream, a, grid_mult);
                 case 12140: return launch_lane<METHOD, 25, 1, 2, 1, 4>(stream, a, grid_mult);
                 case 112140: return launch_lane<METHOD, 25, 1, 2, 1, 4, false, false, 16>(stream, a, grid_mult);
+                case 110011:
+                    if constexpr (METHOD != K_TNCG) { if (lp == 32) return launch_lane<METHOD, 25, 1, 0, 0, 1, true, false, 32>(stream, a, grid_mult); }
+                    break;
             }
         } else if (s_load == 50) {
             if (tx == 48 && key == 10010) return launch_lane<METHOD, 50, 1, 0, 0, 1, false, false, 0, 48>(stream, a, grid_mult);

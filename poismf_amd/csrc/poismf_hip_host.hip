@@ -1702,6 +1702,9 @@ struct HostBarrier {
 //     half) before anybody's copies of M's new rows reach it (those copies follow kernels that waited for that peer's landed event);
 //     and d's own copies of two halves ago are done before d overwrites the same rows again (every peer waited for them before
 //     the half whose landed event d has just waited for).
+//     (TNCG with early stop may skip a half: two CONSECUTIVE halves then update the same factor, and a device may overwrite rows whose
+//     previous copies are still travelling.  Harmless: copies on one copy stream are issued and land in order, every reader of those rows waits for
+//     the LATER half's landed event, and the replica of a peer ends up holding the later rows -- nobody reads in between.)
 // A stream can only wait for an event that has been RECORDED, so the threads hand over "recorded" through an atomic counter per
 // device (a host-side spin for the record CALL of a peer, never for the device); two events per device alternate.
 // Host threads meet at a barrier once per outer iteration (interrupt flag and failures: everybody takes the same decision) and,

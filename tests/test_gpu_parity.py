@@ -354,7 +354,7 @@ def test_long_row_workgroup_path(prec, method, k, monkeypatch):
     (row_eval.hpp, NW > 1), so the path that the power-law tail of config C5 takes is exercised on a small matrix:
     rows with 65 .. ~10^4 nonzeros go through it, shorter ones through the wave-per-row kernel.  (tncg, k = 100) is config C5's own
     instance: half_sweep_kernel<double,tncg,NW=8,streamed> with the compile-time slot count of PMF_LONG_SPECIAL and the
-    hipStreamWaitValue32 hold-back of the other bins (the long rows run on the second stream)."""
+    hold-back of the other bins behind a bounded gate kernel (hold_back_gate_kernel; the long rows run on the second stream)."""
     monkeypatch.setenv("POISMF_HIP_LONGROW_NNZ", "64")
     csr, csc, A0, B0 = H.small_problem(3000, 2000, 120000, k, prec, seed=5, powerlaw=True, empty_rows=(3, 2999))
     assert np.diff(csc[2].astype(np.int64)).max() > 2000
