@@ -1718,6 +1718,9 @@ struct MultiRun {
     std::vector<hipEvent_t> seg_done;                  // "this segment's kernels are done": session stream -> copy stream
     std::vector<hipEvent_t> landed;                    // [2 d + parity]: device d's rows of a half have reached every peer
     std::unique_ptr<std::atomic<unsigned>[]> recorded; // halves of device d whose `landed` event has been recorded
+    std::vector<hipEvent_t> part_done;                 // "this device's share of the column sums' first stage is done": session stream -> copy stream
+    std::vector<hipEvent_t> part_landed;               // [2 d + parity]: device d's partial sums of a half have reached every peer
+    std::unique_ptr<std::atomic<unsigned>[]> part_recorded;
     std::vector<size_t> unchanged;
     std::vector<hipError_t> err;
     std::atomic<int> failed{0};
@@ -1726,9 +1729,10 @@ struct MultiRun {
     MultiRun(const std::vector<int>& devs, size_t dimA, size_t dimB, const sparse_ix* pA, const sparse_ix* pB)
         : nd(devs.size()), devices(devs), rA(balanced_ranges(pA, dimA, devs.size())), rB(balanced_ranges(pB, dimB, devs.size())),
           ss(nd, nullptr), copy_stream(nd, nullptr), seg_done(nd, nullptr), landed(2 * nd, nullptr),
-          recorded(new std::atomic<unsigned>[nd]), unchanged(nd, 0), err(nd, hipSuccess), bar(nd)
+          recorded(new std::atomic<unsigned>[nd]), part_done(nd, nullptr), part_landed(2 * nd, nullptr),
+          part_recorded(new std::atomic<unsigned>[nd]), unchanged(nd, 0), err(nd, hipSuccess), bar(nd)
     {
-        for (size_t d = 0; d < nd; d++) recorded[d].store(0);
+        for (size_t d = 0; d < nd; d++) { recorded[d].store(0); part_recorded[d].store(0); }
     }
     void fail(size_t d)
     {
@@ -1770,6 +1774,9 @@ int run_poismf_multi(const std::vector<int>& devices, real_t* A, real_t* Xr, spa
         HIP_TRY(hipEventCreateWithFlags(&R.seg_done[d], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&R.landed[2 * d], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&R.landed[2 * d + 1], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&R.part_done[d], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&R.part_landed[2 * d], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&R.part_landed[2 * d + 1], hipEventDisableTiming));
         if (want_seg > 1 && poismf_hip_session_set_segments(R.ss[d], 1, want_seg) < 0) return 1;
         for (size_t q = 0; q < nd; q++)   // peer access where the pair allows it (the copies work without, staged by the runtime)
             if (devices[q] != devices[d]) { int can = 0; if (hipDeviceCanAccessPeer(&can, devices[d], devices[q]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devices[q], 0); }
@@ -1782,6 +1789,38 @@ int run_poismf_multi(const std::vector<int>& devices, real_t* A, real_t* Xr, spa
         if (h > 0) {
             if (R.wait_for_peers(d, h - 1)) return 1;
             poismf_hip_session_factors_dirty(s, which ? 0 : 1);   // the fixed factor of this half received rows: its gather copy is re-derived
+        }
+        // The first stage of this half's column sums is shared (poismf_hip_session_colsum_partial): device d sums its share of the
+        // blocks over its whole replica, pushes those partial sums to every peer (copy stream, behind an event of the session stream), and
+        // runs the fixed-order second stage once every peer's share has landed -- the unsharded sum bit for bit, 1 / nd of the first stage
+        // per device.  Ordering: a peer sends its partials of half h only after it has waited for everybody's rows of half h - 1, i.e.
+        // after this device's previous second stage (which read the array) and everything behind it; two events per device alternate,
+        // handed over through a counter as the rows' `landed` events are.  Factors below shard_min rows are summed on every device.
+        static const size_t shard_min = getenv("POISMF_SHARD_COLSUM_MIN_ROWS") ? (size_t)atoll(getenv("POISMF_SHARD_COLSUM_MIN_ROWS")) : (size_t)262144;
+        if (nd > 1 && (which ? dimB : dimA) >= shard_min) {
+            const int nb = poismf_hip_session_colsum_blocks(s, which);
+            const int b_lo = (int)((size_t)nb * d / nd), b_hi = (int)((size_t)nb * (d + 1) / nd);
+            if (poismf_hip_session_colsum_partial(s, which, b_lo, b_hi)) return 1;
+            HIP_TRY(hipSetDevice(devices[d]));
+            HIP_TRY(hipEventRecord(R.part_done[d], s->stream));
+            HIP_TRY(hipStreamWaitEvent(R.copy_stream[d], R.part_done[d], 0));
+            const size_t pbytes = (size_t)(b_hi - b_lo) * k * sizeof(real_t);
+            for (size_t q = 0; q < nd && pbytes > 0; q++) {
+                if (q == d) continue;
+                HIP_TRY(hipMemcpyPeerAsync(poismf_hip_session_partials(R.ss[q]) + (size_t)b_lo * k, devices[q],
+                                           poismf_hip_session_partials(s) + (size_t)b_lo * k, devices[d], pbytes, R.copy_stream[d]));
+            }
+            HIP_TRY(hipEventRecord(R.part_landed[2 * d + (h & 1u)], R.copy_stream[d]));
+            R.part_recorded[d].store(h + 1, std::memory_order_release);
+            for (size_t q = 0; q < nd; q++) {
+                if (q == d) continue;
+                while (R.part_recorded[q].load(std::memory_order_acquire) < h + 1) {
+                    if (R.failed.load()) return 1;
+                    std::this_thread::yield();
+                }
+                HIP_TRY(hipStreamWaitEvent(s->stream, R.part_landed[2 * q + (h & 1u)], 0));
+            }
+            poismf_hip_session_partials_ready(s);
         }
         const int nseg = (int)s->half[which].segs.size();
         R.unchanged[d] = 0;
@@ -1858,6 +1897,8 @@ int run_poismf_multi(const std::vector<int>& devices, real_t* A, real_t* Xr, spa
         if (R.copy_stream[d]) { (void)hipStreamSynchronize(R.copy_stream[d]); (void)hipStreamDestroy(R.copy_stream[d]); }
         if (R.seg_done[d]) (void)hipEventDestroy(R.seg_done[d]);
         for (int e = 0; e < 2; e++) if (R.landed[2 * d + e]) (void)hipEventDestroy(R.landed[2 * d + e]);
+        if (R.part_done[d]) (void)hipEventDestroy(R.part_done[d]);
+        for (int e = 0; e < 2; e++) if (R.part_landed[2 * d + e]) (void)hipEventDestroy(R.part_landed[2 * d + e]);
         poismf_hip_session_destroy(R.ss[d]);
     }
     return rc ? 1 : 0;

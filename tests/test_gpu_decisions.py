@@ -79,8 +79,10 @@ def test_golden_tnc_rows_evaluation_counts(rows, reuse):
           f"largest relative difference in evaluations {worst:.3g}")
     if not use_float:
         # fp64 (measured: 29 of the 30 runs identical in all three numbers, evaluation counts identical in all 30, on the lane engine;
-        # 13 of 15 per `reuse` setting on the register engine, POISMF_HIP_NO_LANE=1 in scripts/knob_matrix.sh)
-        assert same >= total - 2 and worst <= 0.05
+        # 13 of 15 per `reuse` setting on the register engine, POISMF_HIP_NO_LANE=1 in scripts/knob_matrix.sh -- 12 of 15 since round 5, where
+        # TNCG's non-resident rows take the eight-wave streamed kernel: one more of the 300-nonzero rows ends an evaluation earlier or later)
+        slack = 3 if os.environ.get("POISMF_HIP_NO_LANE") else 2
+        assert same >= total - slack and worst <= 0.05
     # fp32 TNC is chaotic in the reference itself (tests/test_gpu_rows.py): counts are reported, not asserted
 
 
