@@ -129,7 +129,7 @@ __device__ __forceinline__ unsigned acc_get(unsigned a)
 // nothing per dimension, the reference's own summation order.  The dots read the same image (lane j its own row, one ds_read_b128
 // per slot, row stride 816 bytes = conflict-free), so NO tile lives in registers: the solver's state has the 256 architectural
 // registers to itself and the v_accvgpr traffic is gone.  TX_ = rows of the image: 48 (39 KB: four rows per CU) or 64 (52 KB: three).
-template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0, int TX_ = 0> struct LaneEval {
+template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0, int TX_ = 0, bool TM_ = false> struct LaneEval {
     using SA = typename Slot<T>::A;
     static constexpr int SN = Slot<T>::N;                 // elements per 16-byte slot
     static constexpr int KP = KS * SN;                    // elements of a factor row, padded to whole slots
@@ -282,7 +282,14 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     unsigned zero_row;
     int k, ldF;
     int lane, wid;
-    static constexpr int member = 0;
+    int member;          // TM_: this workgroup's place in its team (0 otherwise)
+    int tm_M;            // TM_: members of the team
+    unsigned tm_seq;     // TM_: exchanges so far
+    unsigned long long* tm_words;   // TM_: the team's exchange area (row_eval.hpp, team_sum)
+    unsigned* tm_err;
+    unsigned tm_spin;
+    static constexpr unsigned TEAM_ROUND = 4;   // a member's share of a row is a whole number of these
+    static_assert(!TM_ || (NW_ > 1 && sizeof(T) == 8), "lane teams: doubles, several waves per member");
     struct ElemOf {   // factor dimension held in element i of this lane (only meaningful where act[i])
         int d0;
         __device__ __forceinline__ int operator[](int i) const { return d0 + DB * i; }
@@ -311,6 +318,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     {
         lane = lane_id();
         wid = NW > 1 ? (int)(threadIdx.x / WAVE) : 0;
+        if constexpr (TM_) wid = (int)uniform((unsigned)wid);   // (a scalar to the compiler too: `if (wid == 0)` around the team exchange is a scalar branch)
         const int col = lane & 15, rr = lane >> 4;
         elem.d0 = XPOSE ? lane : col + CW * rr;
         const bool lane_on = XPOSE ? lane < DB : (col < CW && elem.d0 < DB);
@@ -339,6 +347,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         pbuf = (T*)(size_t)16; qbuf = (T*)(size_t)32;   // tags, never dereferenced
         n_eval = 0;
         nnz = 0;
+        member = 0; tm_M = 1; tm_seq = 0; tm_words = nullptr; tm_err = nullptr; tm_spin = TEAM_SPIN_LIMIT;
     }
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
 
@@ -472,7 +481,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     }
     __device__ __forceinline__ void store_vec(T* p, const T (&x)[NC]) const
     {
-        if (wid == 0) {
+        if (wid == 0 && member == 0) {
 #pragma unroll
             for (int i = 0; i < NC; i++)
                 if (act[i]) p[elem[i]] = x[i];
@@ -1058,7 +1067,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #pragma unroll
                 for (int i = 0; i < NC; i++) xv[(wid * NC + i) * WAVE + lane] = tot[i];
             }
-            if (lane == 0) xl[wid] = lsum;
+            if (TM_ || lane == 0) xl[wid] = lsum;   // (TM_: no lane-divergent region between here and the team exchange, see team_sum)
             __syncthreads();
             double lp[NW];
 #pragma unroll
@@ -1081,7 +1090,35 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                     tot[i] = s;
                 }
             }
+            if constexpr (TM_) team_exchange(tot, lsum, vec);
         }
+    }
+    // TM_, every wave of the member, after the member's own waves have been added up (tot / lsum identical in all of them): the member's sums
+    // cross the team (row_eval.hpp, team_sum: tagged granules, member order); the totals reach the other waves through the cross-wave
+    // scratch -- the set the NEXT combine writes -- between two barriers.
+    __device__ __forceinline__ void team_exchange(T (&tot)[NC], double& lsum, bool vec)
+    {
+        tm_seq++;
+        T* xv = (T*)(xw_base + xw_sel * XW_BYTES);
+        double* xl = (double*)(xw_base + xw_sel * XW_BYTES + NW * WAVE * NC * (int)sizeof(T));
+        if (wid == 0) {
+            TeamVals<NC> x;
+#pragma unroll
+            for (int i = 0; i < NC; i++) { x.idx[i] = act[i] ? elem[i] : 0; x.valid[i] = vec && act[i]; x.v[i] = (double)tot[i]; }
+            x.s = lsum;
+            x.ok = true;
+            x = team_sum_call<NC>(tm_words, tm_M, member, tm_seq, tm_err, tm_spin, lane, x);   // (out of line: see row_eval.hpp)
+#pragma unroll
+            for (int i = 0; i < NC; i++) xv[i * WAVE + lane] = (T)x.v[i];
+            xl[0] = x.s;
+        }
+        __syncthreads();
+        lsum = xl[0];
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) tot[i] = act[i] ? xv[i * WAVE + lane] : (T)0;
+        }
+        __syncthreads();
     }
 
     // Same contract as RegEval::eval

@@ -64,6 +64,7 @@ template <class T> struct HalfArgs {
     unsigned long long* team_buf;     // team launches (several CUs per row, reg_eval.hpp M_ > 1): arrival counters, mailboxes, exchange slots
     unsigned* team_err;               // set by a team launch that gave up (an exchange timed out); the host re-runs such a launch
     unsigned team_spin;               // polls (~1 us each) before a team member gives the launch up (TEAM_SPIN_LIMIT; a knob for tests)
+    unsigned team_members;            // giant-row / lane teams (row_eval.hpp TM, lane_eval.hpp TM_): workgroups per row
     const unsigned* gate;             // != nullptr: the kernel runs only if *gate != 0 (the streamed re-run of a team launch that gave up)
     unsigned* arrive;                 // != nullptr (the long-row launch on the second stream): every workgroup counts itself in here when it
                                       // starts -- the main stream holds the other bins' kernels back until the long rows are on the chip

@@ -310,56 +310,62 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
 #endif
 }
 
-// Giant rows (row_eval.hpp, TM): a team of GT_M eight-wave workgroups per row.  A workgroup joins the next open team in ARRIVAL order (whatever
-// the dispatcher and the other kernels on the chip do, a team's members are resident); the team's first member draws rows from the launch's
-// queue (longest first) and posts each ticket in the team's mailbox, the others pick it up there.  Member m streams nonzeros [m S, (m + 1) S) of
-// the row as if they were a row of their own; RowEval::team_exchange adds the members' sums per evaluation.  An exchange that times out sets the
-// launch's error word: everybody leaves, and the host re-runs the launch's rows on the one-workgroup kernel (as for the register teams).
-template <class T, int NC, int METHOD, int SL, int NW>
-__global__ __launch_bounds__(WAVE* NW) void half_sweep_giant_kernel(const HalfArgs<T> a)
+// Rows shared by a TEAM of workgroups whose members exchange their sums per evaluation (row_eval.hpp: team_sum).  Two engines take part: the
+// streamed LDS engine for giant rows (RowEval TM: GT_M = 32 eight-wave workgroups per row above 8192 nonzeros) and the lane engine for k = 100
+// fp64 rows of 385 .. 8192 nonzeros (LaneEval TM_: ceil(class / 384) four-wave workgroups, each keeping its share of the row RESIDENT).  A
+// workgroup joins the next open team in ARRIVAL order (whatever the dispatcher and the other kernels on the chip do, a team's members are
+// resident); the team's first member draws rows from the launch's queue (longest first) and posts each ticket in the team's mailbox, the others
+// pick it up there.  Member m takes nonzeros [m S, (m + 1) S) of the row, S = ceil(nnz / M) rounded up to the engine's grain, as if they were a
+// row of their own.  An exchange that times out sets the launch's error word: everybody leaves, and the host re-runs the launch's rows on the
+// one-workgroup streamed kernel (as for the register teams).
+template <class EV, class T, int NC, int METHOD>
+__device__ __forceinline__ void team_rows(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
-    using EV = RowEval<T, NC, SL, NW, PF, true>;
-    EV ev;
     if (a.arrive != nullptr && threadIdx.x == 0) atomicAdd(a.arrive, 1u);
     ev.init(a.geom, a.F, smem);
     T bs[NC];
     ev.load_vec(a.bsum, bs);
     const RowDesc* desc = a.desc + a.perm_begin;
+    const unsigned M = a.team_members;
     unsigned* box = ev.ticket_slot();
     if (threadIdx.x == 0) {
         const unsigned n = atomicAdd((unsigned*)a.team_buf, 1u);
-        box[0] = n / (unsigned)GT_M;
-        box[1] = n % (unsigned)GT_M;
+        box[0] = n / M;
+        box[1] = n % M;
     }
     __syncthreads();
     const unsigned team = uniform(box[0]);
     ev.member = (int)uniform(box[1]);
     __syncthreads();
-    if (team >= GT_TEAMS_MAX) return;   // (the host never launches that many)
-    ev.tm_words = a.team_buf + GT_HEAD_WORDS + (size_t)team * GT_TEAM_WORDS;
+    if ((size_t)(team + 1) * gt_team_words(M) + GT_HEAD_WORDS > GT_BUF_BYTES / 8) return;   // (the host never launches that many)
+    ev.tm_M = (int)M;
+    ev.tm_seq = 0;
+    ev.tm_words = a.team_buf + GT_HEAD_WORDS + (size_t)team * gt_team_words(M);
     ev.tm_err = a.team_err;
     ev.tm_spin = a.team_spin;
     unsigned long long* mail = ev.tm_words;   // [2]: { row number << 32 | ticket } of the row with that parity
     constexpr unsigned END = 0xffffffffu;
     for (unsigned rowno = 1;; rowno++) {
-        if (threadIdx.x == 0) {
+        // (all 64 lanes of the first wave poll and post: no lane-divergent region around the waits -- row_eval.hpp, team_sum, on why)
+        if (ev.wid == 0) {
             unsigned tk = END;
             if (ev.member == 0) {
-                tk = take_ticket<METHOD>(a);
-                if (tk >= a.nrows || __hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) tk = END;
+                unsigned t0 = 0;
+                if (ev.lane == 0) t0 = take_ticket<METHOD>(a);
+                tk = uniform(t0);
+                if (tk >= a.nrows || uniform(__hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) tk = END;
                 gt_store(mail + (rowno & 1u), ((unsigned long long)rowno << 32) | tk);
             } else {
                 // (a member whose leader has not arrived yet waits as long as other teams keep the queue moving or rows remain; the
                 // time-out applies once nothing moves)
-                unsigned seen = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned seen = uniform(__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 for (unsigned spins = 0;; spins++) {
                     const unsigned long long v = gt_load(mail + (rowno & 1u));
-                    if ((unsigned)(v >> 32) == rowno) { tk = (unsigned)v; break; }
+                    const unsigned hi = uniform((unsigned)(v >> 32)), lo = uniform((unsigned)v);
+                    if (hi == rowno) { tk = lo; break; }
                     if ((spins & 255u) == 255u) {
-                        if (__hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                        const unsigned q = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (uniform(__hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+                        const unsigned q = uniform(__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         if (q != seen) { seen = q; spins = 0; }
                         else if (rowno == 1u && q >= a.nrows) break;   // every row has an owner and this team never got a leader: nothing to do
                     }
@@ -376,12 +382,29 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_giant_kernel(const HalfAr
         const RowDesc d = desc[t];
         const unsigned nnz = uniform(d.nnz);
         const unsigned long long p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
-        const unsigned S = ((nnz + (unsigned)GT_M - 1u) / (unsigned)GT_M + 63u) & ~63u;
+        const unsigned S = ((nnz + M - 1u) / M + (EV::TEAM_ROUND - 1u)) / EV::TEAM_ROUND * EV::TEAM_ROUND;
         const unsigned off = (unsigned)ev.member * S;
         const unsigned mine = off < nnz ? (nnz - off < S ? nnz - off : S) : 0u;
         ev.begin_row(a.indices + p0 + (mine ? off : 0u), a.values + p0 + (mine ? off : 0u), mine);
         solve_row<EV, T, NC, METHOD>(a, ev, bs, uniform(d.lrow), nnz);
     }
+}
+template <class T, int NC, int METHOD, int SL, int NW>
+__global__ __launch_bounds__(WAVE* NW) void half_sweep_giant_kernel(const HalfArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
+    using EV = RowEval<T, NC, SL, NW, PF, true>;
+    EV ev;
+    team_rows<EV, T, NC, METHOD>(a, ev, smem);
+}
+template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, int LP>
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void half_sweep_lane_team_kernel(const HalfArgs<T> a)
+{
+    using EV = LaneEval<T, KS, LV, LA, LL, NW, false, false, LP, 0, true>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
+    EV ev;
+    team_rows<EV, T, EV::NC, METHOD>(a, ev, smem);
 }
 
 // Waves per SIMD the register allocator is asked to make room for: the largest count whose VGPR budget (512 per SIMD
@@ -762,6 +785,18 @@ template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false
         return 0;
     } else return 1;
 }
+// lane teams: k = 100 fp64 TNCG rows of 385 .. 8192 nonzeros, M = a.team_members four-wave workgroups per row
+int launch_lane_team(hipStream_t stream, int method, int s_load, int lv, int la, int ll, int nw, int lp, const HalfArgs<real_t>& a, unsigned grid)
+{
+    if constexpr (tu_has(K_TNCG) && sizeof(real_t) == 8) {
+        if (method == POISMF_TNCG && s_load == 50 && lv == 1 && la == 0 && ll == 0 && nw == 4 && lp == 32) {
+            hipLaunchKernelGGL((half_sweep_lane_team_kernel<real_t, K_TNCG, 50, 1, 0, 0, 4, 32>), dim3(grid), dim3(WAVE * 4), 0, stream, a);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
+    return 1;
+}
 template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int lv, int la, int ll, int nw, int small, int lp, int tx, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     const int key = (((lv * 10 + la) * 10 + ll) * 10 + nw) * 10 + small + (lp > 0 ? 100000 : 0);
@@ -878,6 +913,7 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
     int rc = 1;
     t_device = o.device; t_num_cu = o.num_cu;
     if (o.lane_L > 0) {
+        if (o.team > 1) return launch_lane_team(o.main_stream, method, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_LP, a, o.grid);
         if (method == POISMF_PG) return launch_lane_shape<K_PG>(o.main_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_tx, a, o.grid_mult);
         if (method == POISMF_CG) return launch_lane_shape<K_CG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_tx, a, o.grid_mult);
         if (method == POISMF_TNCG) return launch_lane_shape<K_TNCG>(o.nw > 1 ? o.main_stream : o.bin_stream, o.s_load, o.lane_L, o.lane_A, o.lane_LL, o.nw, o.lane_small, o.lane_LP, o.lane_tx, a, o.grid_mult);

@@ -242,10 +242,14 @@ struct poismf_hip_session {
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
     unsigned long long* d_giant = nullptr;  // giant-row team launches (row_eval.hpp, GT_*): allocated by the first one
+    unsigned long long* d_lane_team = nullptr;   // lane-team launches (same layout; they follow one another on the main stream, beside the giant rows' launch)
     unsigned* d_arrive = nullptr;           // workgroups of the forked long-row launch that have started (half_sweep_impl)
     unsigned long long gate_budget = 200000;   // ticks of the wall clock the hold-back gate waits at most: 2 ms (session_alloc)
-    unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far
+    unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far; [2], [3]: the same for the
+                                            // giant-row launch, which runs on the second stream BESIDE the main stream's team launches (its own error word, its own buffer)
     real_t* d_team_backup = nullptr;        // the rows a team launch starts from (restored before its re-run)
+    real_t* d_giant_backup = nullptr;       // the same for the giant-row launch (second stream: its own copy)
+    size_t giant_backup_elems = 0;
     size_t team_backup_elems = 0;
     bool team_launched = false;             // since the words were last read
     int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
@@ -682,8 +686,8 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 24), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs)
     if (pmf_alloc(&s->d_arrive, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (pmf_alloc(&s->d_team_err, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_team_err, 4 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->d_team_err, 0, 4 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (cached_stream(device, &s->aux_stream)) return fail();
     if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) return fail();
     if (hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail();
@@ -804,10 +808,12 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     pmf_free(s->d_counter, s->stream);
     pmf_free(s->d_queue, s->stream);
     pmf_free(s->d_giant, s->stream);
+    pmf_free(s->d_lane_team, s->stream);
     pmf_free(s->d_team, s->stream);
     pmf_free(s->d_team_err, s->stream);
     pmf_free(s->d_arrive, s->stream);
     pmf_free(s->d_team_backup, s->stream);
+    pmf_free(s->d_giant_backup, s->stream);
     (void)hipStreamSynchronize(s->stream);   // the stream-ordered frees have run
     if (aux) release_stream(s->device, aux);
     if (own) release_stream(s->device, own);
@@ -882,13 +888,13 @@ int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, 
 static int team_check(poismf_hip_session* s)
 {
     if (!s->team_launched) return 0;
-    unsigned w[2] = { 0, 0 };
-    HIP_TRY(pmf_download(w, s->d_team_err, 2 * sizeof(unsigned), s->stream));
+    unsigned w[4] = { 0, 0, 0, 0 };
+    HIP_TRY(pmf_download(w, s->d_team_err, 4 * sizeof(unsigned), s->stream));
     s->team_launched = false;
-    if (w[1] != 0) {
+    if (w[1] + w[3] != 0) {
         fprintf(stderr, "poismf_hip: %u multi-CU row launch(es) timed out waiting for a partner CU and were re-run on the streamed path "
-                        "(results are valid; another process or kernel is holding CUs)\n", w[1]);
-        HIP_TRY(hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream));
+                        "(results are valid; another process or kernel is holding CUs)\n", w[1] + w[3]);
+        HIP_TRY(hipMemsetAsync(s->d_team_err, 0, 4 * sizeof(unsigned), s->stream));
     }
     return 0;
 }
@@ -1117,12 +1123,24 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             // to 384 nonzeros has a resident instance and the streamed launch keeps the 3 k rows above.  POISMF_HIP_K100_LANE_B=0: as in round 4
             static const bool k100_lane_b = getenv("POISMF_HIP_K100_LANE_B") == nullptr || atoi(getenv("POISMF_HIP_K100_LANE_B")) != 0;
             if (sizeof(real_t) == 8 && g.s_load == 50 && b.cls > 64 && which == 0 && !k100_lane_b) ls.waves = 0;
+            // k = 100 fp64 under TNCG, rows of 385 .. 8192 nonzeros (round 5): a TEAM of ceil(class / 384) four-wave workgroups keeps the row
+            // RESIDENT (each member its 1/M of the nonzeros in one register set + a partial LDS set per wave, lane_eval.hpp TM_) and the members
+            // exchange their sums per evaluation -- instead of re-streaming 800 bytes per nonzero for each of ~70 evaluations (84 % of config C5's
+            // 697 GB per sweep).  The team size is a function of the row's length class alone.  POISMF_HIP_NO_LANE_TEAMS=1: the eight-wave
+            // streamed kernel (round 5a)
+            int lane_team = 0;
+            static const bool no_lane_teams = getenv("POISMF_HIP_NO_LANE_TEAMS") != nullptr;
+            if (ls.waves == 0 && sizeof(real_t) == 8 && g.s_load == 50 && pm == POISMF_TNCG && !no_lane_teams && !no_team && !static_rows_ && b.cls > 384 &&
+                b.cls <= LONG_ROW_NNZ && launches.size() < (size_t)MAX_LAUNCHES - 2) {
+                const int m = (int)((b.cls + 383u) / 384u);
+                if (m >= 2 && s->num_cu >= 2 * m) { ls = LaneShape{ 1, 0, 0, 4, 0, 32 }; lane_team = m; }
+            }
             if (ls.waves > 0) {
-                if (!launches.empty() && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp && launches.back().lane_tx == ls.tx &&
+                if (!launches.empty() && launches.back().team == lane_team && launches.back().lane_L == ls.lv && launches.back().lane_A == ls.la && launches.back().lane_LL == ls.ll && launches.back().lane_small == ls.small && launches.back().lane_LP == ls.lp && launches.back().lane_tx == ls.tx &&
                     launches.back().nw == ls.waves && launches.back().begin + launches.back().count == b.begin)
                     { launches.back().count += b.count; launches.back().nnz += b.nnz; }
                 else {
-                    launches.push_back({ b.begin, b.count, g, ls.waves, 0, 0, b.nnz });
+                    launches.push_back({ b.begin, b.count, g, ls.waves, 0, lane_team, b.nnz });
                     launches.back().lane_L = ls.lv; launches.back().lane_A = ls.la; launches.back().lane_LL = ls.ll; launches.back().lane_small = ls.small; launches.back().lane_LP = ls.lp; launches.back().lane_tx = ls.tx;
                 }
                 continue;
@@ -1223,7 +1241,11 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     bool any_long = false;
     for (const Launch& L : launches) any_long = any_long || (L.nw > 1 && L.reg_S == 0 && L.lane_L == 0);
     const bool forked = !no_fork && launches.size() > 1 && (any_long || fork_bins);
-    hipStream_t long_stream = forked ? s->aux_stream : s->stream;
+    // (two TEAM launches must never run beside each other: each waits for partners that need the CUs the other's partial teams hold -- with lane
+    // teams in the half, the giant rows' launch stays on the main stream, in front of them)
+    bool any_lane_team = false;
+    for (const Launch& L : launches) any_lane_team = any_lane_team || (L.team > 1 && L.lane_L > 0);
+    hipStream_t long_stream = (forked && !any_lane_team) ? s->aux_stream : s->stream;
     double queued[2] = { 0.0, 0.0 };
     // The long rows go to the second stream to run NEXT TO the other bins, not after them.  The other bins' kernels are persistent
     // (a workgroup keeps its CU until the bin's queue is empty): whichever kernel reaches the chip first fills it, and on config C5
@@ -1232,7 +1254,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // that count (a one-wave gate kernel with a time limit, above; rounds 3-4a: hipStreamWaitValue32) before it launches anything else.
     // Arrivals only ever grow, so a chip that cannot hold the whole launch at once delays the main stream by the gate's 2 ms, no more.
     static const bool no_arrive = getenv("POISMF_HIP_NO_ARRIVE_WAIT") != nullptr;   // testing knob
-    const bool hold_back = forked && any_long && !no_arrive;
+    const bool hold_back = forked && any_long && !no_arrive && !any_lane_team;
     if (hold_back) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, sizeof(unsigned), s->stream));
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
@@ -1247,7 +1269,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             char txt[192];
             const char* m = is_pg ? "pg" : p->method == POISMF_EVAL ? "eval" : pm == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
-            if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP == 32 ? "+32" : L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.lane_tx == 48 ? ",TX=48" : L.lane_tx == 64 ? ",TX=64" : "", L.count);
+            if (L.lane_L > 0 && L.team > 1) snprintf(txt, sizeof txt, "half_sweep_lane_team_kernel<%s,%s,KS=%d,V=%d,L=0+%d,NW=%d,M=%d> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_LP, L.nw, L.team, L.count);
+            else if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP == 32 ? "+32" : L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.lane_tx == 48 ? ",TX=48" : L.lane_tx == 64 ? ",TX=64" : "", L.count);
             else if (L.team == GT_M && L.reg_S == 0) snprintf(txt, sizeof txt, "half_sweep_giant_kernel<%s,%s,NW=%d,M=%d,streamed cap=%d> rows=%u;", t, m, L.nw, L.team, L.geom.cap, L.count);
             else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
             else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
@@ -1275,7 +1298,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         const bool one_wave_reg = (L.reg_S > 0 || L.lane_L > 0) && L.nw == 1;
         if (one_wave_reg) a.queue = nullptr;
         a.team_buf = nullptr; a.team_err = s->d_team_err;
-        const bool giant = L.team == GT_M && L.reg_S == 0;
+        unsigned* terr = s->d_team_err;
+        const bool giant = L.team == GT_M && L.reg_S == 0 && L.lane_L == 0;
+        const bool lane_team = L.team > 1 && L.lane_L > 0;
+        a.team_members = (unsigned)std::max(1, L.team);
         // (a giant-row team launch and everything that brackets it -- the copy of its rows, their restoration and re-run -- lives on the stream
         // the long rows run on)
         hipStream_t tst = giant ? long_stream : s->stream;
@@ -1284,10 +1310,12 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 a.queue = s->d_queue + MAX_LAUNCHES + (launch_no % 8);
                 HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(unsigned), s->stream));
             }
-            if (giant) {
-                if (s->d_giant == nullptr && pmf_alloc(&s->d_giant, (size_t)GT_BUF_BYTES, s->stream) != hipSuccess) return 1;
-                HIP_TRY(hipMemsetAsync(s->d_giant, 0, (size_t)GT_BUF_BYTES, tst));
-                a.team_buf = s->d_giant;
+            if (giant || lane_team) {
+                unsigned long long*& buf = giant ? s->d_giant : s->d_lane_team;
+                if (buf == nullptr && pmf_alloc(&buf, (size_t)GT_BUF_BYTES, s->stream) != hipSuccess) return 1;
+                HIP_TRY(hipMemsetAsync(buf, 0, (size_t)GT_BUF_BYTES, tst));
+                a.team_buf = buf;
+                if (giant) { terr = s->d_team_err + 2; a.team_err = terr; }
             } else {
                 if (s->d_team == nullptr && pmf_alloc(&s->d_team, (size_t)TEAM_BUF_BYTES, s->stream) != hipSuccess) return 1;
                 HIP_TRY(hipMemsetAsync(s->d_team, 0, (size_t)TEAM_BUF_BYTES, s->stream));
@@ -1296,14 +1324,20 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             s->team_launched = true;
             // the rows this launch starts from, in case it gives up
             const size_t need = (size_t)L.count * s->k;
-            if (need > s->team_backup_elems) {
-                pmf_free(s->d_team_backup, s->stream);
-                s->d_team_backup = nullptr; s->team_backup_elems = 0;
-                HIP_TRY(pmf_alloc(&s->d_team_backup, need * sizeof(real_t), s->stream));
-                s->team_backup_elems = need;
+            real_t*& backup = giant ? s->d_giant_backup : s->d_team_backup;
+            size_t& backup_elems = giant ? s->giant_backup_elems : s->team_backup_elems;
+            if (need > backup_elems) {
+                // (sized for the largest team launch of this half at once: growing it launch by launch would free -- i.e. synchronise the device -- each time)
+                size_t want = need;
+                for (const Launch& L2 : launches)
+                    if (L2.team > 1 && (L2.team == GT_M && L2.reg_S == 0 && L2.lane_L == 0) == giant) want = std::max(want, (size_t)L2.count * s->k);
+                pmf_free(backup, s->stream);
+                backup = nullptr; backup_elems = 0;
+                HIP_TRY(pmf_alloc(&backup, want * sizeof(real_t), s->stream));
+                backup_elems = want;
             }
             hipLaunchKernelGGL(team_save_rows_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, (size_t)s->num_cu * 8)), dim3(256), 0, tst,
-                               M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, s->d_team_backup);
+                               M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, backup);
         }
         a.gate = nullptr;
         const bool is_long = L.nw > 1 && L.reg_S == 0 && L.lane_L == 0;
@@ -1327,6 +1361,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             const unsigned teams = std::max(1u, std::min(std::min((unsigned)L.count, want), std::min((unsigned)GT_TEAMS_MAX, (unsigned)s->num_cu / (unsigned)GT_M)));
             grid = teams * (unsigned)GT_M;
         }
+        if (lane_team) grid = std::max(1u, std::min((unsigned)L.count, (unsigned)s->num_cu / (unsigned)L.team)) * (unsigned)L.team;   // whole teams, one workgroup per CU
         int rc = 1;
         // (with long rows on the second stream, the one-wave bins that follow go wherever less work is queued: on C5 the lane rows
         // run behind the giant rows on the second stream while the mid-length bin has the main one)
@@ -1362,23 +1397,36 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 // if the team launch gave up: rows back to where they started, the same rows on the streamed LDS kernel, note it
                 hipLaunchKernelGGL(team_restore_rows_kernel, dim3((unsigned)std::min<size_t>(((size_t)L.count * s->k + 255) / 256, (size_t)s->num_cu * 8)),
                                    dim3(256), 0, tst, M, Mp, (int)s->ld, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k,
-                                   s->d_team_backup, s->d_team_err);
+                                   giant ? s->d_giant_backup : s->d_team_backup, terr);
                 HalfArgs<real_t> af = a;
                 // (a.geom is the LDS engine's geometry for the launch's longest length class: what these rows take without teams)
                 af.team_buf = nullptr;
-                af.gate = s->d_team_err;
+                af.gate = terr;
                 af.arrive = nullptr;
                 af.queue = s->d_queue + MAX_LAUNCHES + 8 + (launch_no % 8);
                 HIP_TRY(hipMemsetAsync(af.queue, 0, sizeof(unsigned), tst));
+                if (lane_team) {   // (a lane launch carries the one-wave LDS geometry of its class: the eight-wave streamed kernel wants its own)
+                    af.geom.resident = 0;
+                    af.geom.prefetch = prefetch_enabled() ? 1 : 0;
+                    af.geom.pq_cap = 0;
+                    for (int cap = 128;; cap -= 16) {
+                        af.geom.cap = cap;
+                        if (cap <= 16 || lds_bytes_per_block(af.geom, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
+                    }
+                }
                 OneLaunch of = o;
-                of.reg_S = 0; of.nw = giant ? LONG_NW : 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0; of.lane_LP = 0; of.lane_tx = 0;
+                of.reg_S = 0; of.nw = (giant || lane_team) ? LONG_NW : 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0; of.lane_LP = 0; of.lane_tx = 0;
                 of.s_load = af.geom.s_load;
                 of.bin_stream = tst; of.long_stream = tst;
                 of.lds = lds_bytes_per_block(af.geom, sizeof(real_t), of.nw);
-                of.grid = giant ? (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu)
+                of.grid = (giant || lane_team) ? (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu)
                                 : (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / of.lds)) * 2);
+#ifdef PMF_LANE_ONLY   // (development builds without the streamed kernels: no re-run)
+                rc = 0;
+#else
                 rc = launch_one(p->method, of, af);
-                hipLaunchKernelGGL(team_fold_err_kernel, dim3(1), dim3(1), 0, tst, s->d_team_err);
+#endif
+                hipLaunchKernelGGL(team_fold_err_kernel, dim3(1), dim3(1), 0, tst, terr);
             }
             if (s->profiling) {
                 HIP_TRY(hipEventRecord(lr.t1, lst));

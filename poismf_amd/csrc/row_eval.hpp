@@ -65,14 +65,123 @@ constexpr unsigned TEAM_SPIN_LIMIT = 1u << 20;   // polls (~1 us each) before a 
 // Buffer (8-byte words): [0] arrival counter, then per team { mailbox[2], exchange[2 parities][GT_M members][GT_GRAN granules] }.
 constexpr int GT_M = 32;                           // members of a giant-row team (a function of nothing: a row's arithmetic must not depend on its launch)
 constexpr int GT_VALS = 258;                       // doubles per exchange: a k-vector of up to 256 elements (k <= 256 fp64 / 512 fp32: two exchanges' worth is never needed) + the sum
-constexpr unsigned GT_GRAN = 2 * GT_VALS;
-constexpr unsigned GT_HEAD_WORDS = 8;
-constexpr unsigned GT_TEAM_WORDS = 2 + 2 * GT_M * GT_GRAN + 2;
+constexpr unsigned GT_PAD_AT = 2 * GT_VALS;          // first of a member's pad granules: where lanes that carry no value of their own publish (team_sum)
+constexpr unsigned GT_PAD_WORDS = 32;
+constexpr unsigned GT_GRAN = (2 * GT_VALS + GT_PAD_WORDS + 15) / 16 * 16;   // words per member and set, whole 128-byte lines (no line is written by two members)
+constexpr unsigned GT_HEAD_WORDS = 16;
+constexpr unsigned GT_MAIL_WORDS = 16;   // a team's mailbox[2], a line of its own
+constexpr unsigned GT_TEAM_WORDS = GT_MAIL_WORDS + 2 * GT_M * GT_GRAN;
+__host__ __device__ constexpr unsigned gt_team_words(unsigned members) { return GT_MAIL_WORDS + 2u * members * GT_GRAN; }   // (teams of other sizes share the buffer: lane_eval.hpp, TM_)
 constexpr unsigned GT_TEAMS_MAX = 16;
 constexpr unsigned long long GT_BUF_BYTES = 8ull * (GT_HEAD_WORDS + (unsigned long long)GT_TEAMS_MAX * GT_TEAM_WORDS);
 __device__ __forceinline__ void gt_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long gt_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// One exchange of a team of `M` workgroups, carried out by ONE wave of each member (all 64 lanes call it): lane-local values val[i] (valid[i]:
+// this lane carries one; idx[i] < GT_VALS - 1: its place in the member's vector) and one wave-uniform scalar are published as tagged granules,
+// the other members' are collected and everything is added in MEMBER ORDER (every member ends with the same bits).  Two alternating sets of
+// granules per member (a member can be at most one exchange ahead of the slowest).  The collection is pipelined four members deep: the loads of
+// members m + 1 .. m + 3 are in flight while member m's tags are checked (a team of 32 took ~25 us per exchange one member at a time); a member
+// whose granules are not there yet is polled on its own.  `words`: the team's area { mailbox[2], granules[2 parities][M][GT_GRAN] }.
+// Returns false when an exchange timed out (the launch's error word is set: everybody leaves, the host re-runs the launch's rows).
+template <int NV>
+__device__ __forceinline__ bool team_sum(unsigned long long* words, int M, int member, unsigned seq, unsigned* err, unsigned spin_limit, int lane,
+                                         const int (&idx)[NV], const bool (&valid)[NV], double (&val)[NV], double& scal)
+{
+    static_assert(2 * NV <= (int)GT_PAD_WORDS, "one pad granule per value");
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    unsigned long long* slots = words + GT_MAIL_WORDS + (size_t)(seq & 1u) * (size_t)M * GT_GRAN;
+    unsigned long long* mine = slots + (size_t)member * GT_GRAN;
+    // NO lane-dependent branch in here: a lane without a value of its own publishes and collects a PAD granule (tagged like the others, so
+    // its polls succeed with everybody else's) and the scalar is stored and loaded by all 64 lanes.  Under a 512-register tile the compiler
+    // spills around this code, and a spill placed inside a lane-divergent region saves only the active lanes' copies: the others came back
+    // with the previous exchange's values (measured: a member re-publishing its previous sum -- rarely, box to box).
+    unsigned at[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) at[i] = valid[i] ? 2u * (unsigned)idx[i] : GT_PAD_AT + 2u * (unsigned)i;
+    constexpr unsigned SCAL_AT = 2u * (GT_VALS - 1);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, val[i]);
+        gt_store(mine + at[i], (b & 0xffffffffull) | tag);
+        gt_store(mine + at[i] + 1, (b >> 32) | tag);
+    }
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, scal);
+        gt_store(mine + SCAL_AT, (b & 0xffffffffull) | tag);
+        gt_store(mine + SCAL_AT + 1, (b >> 32) | tag);
+    }
+    constexpr int DEPTH = 4;
+    unsigned long long lo[DEPTH][NV], hi[DEPTH][NV], l0[DEPTH], l1[DEPTH];
+    auto request = [&](int m, int slot) {   // (wave-uniform condition; own member and past the last: nothing to load)
+        if (m != member && m < M) {
+            const unsigned long long* theirs = slots + (size_t)m * GT_GRAN;
+#pragma unroll
+            for (int i = 0; i < NV; i++) { lo[slot][i] = gt_load(theirs + at[i]); hi[slot][i] = gt_load(theirs + at[i] + 1); }
+            l0[slot] = gt_load(theirs + SCAL_AT); l1[slot] = gt_load(theirs + SCAL_AT + 1);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++) { lo[slot][i] = tag; hi[slot][i] = tag; }
+            l0[slot] = tag; l1[slot] = tag;
+        }
+    };
+    double sum[NV], lt = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) sum[i] = 0.0;
+    bool dead = false;
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; d++) request(d, d);
+    for (int m0 = 0; m0 < M; m0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int m = m0 + d;
+            request(m + DEPTH - 1, (d + DEPTH - 1) % DEPTH);
+            if (m < M) {
+                double pv[NV], pl = scal;
+#pragma unroll
+                for (int i = 0; i < NV; i++) pv[i] = val[i];
+                if (m != member && !dead) {
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool ok = (l0[d] >> 32) == seq && (l1[d] >> 32) == seq;
+#pragma unroll
+                        for (int i = 0; i < NV; i++) ok = ok && (lo[d][i] >> 32) == seq && (hi[d][i] >> 32) == seq;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((++spins & 255u) == 0 && (spins > spin_limit || uniform(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0)) {
+                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            dead = true;
+                            break;
+                        }
+                        request(m, d);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NV; i++) pv[i] = __builtin_bit_cast(double, (lo[d][i] & 0xffffffffull) | (hi[d][i] << 32));
+                    pl = uniform(__builtin_bit_cast(double, (l0[d] & 0xffffffffull) | (l1[d] << 32)));
+                }
+#pragma unroll
+                for (int i = 0; i < NV; i++) sum[i] = m == 0 ? pv[i] : sum[i] + pv[i];
+                lt = m == 0 ? pl : lt + pl;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) val[i] = sum[i];
+    scal = lt;
+    return !dead;
+}
+
+
+// The same exchange OUT OF LINE, for kernels whose registers are full (the lane engine's resident teams, 512 registers + scratch): compiled on
+// its own it has no spills, and what the caller spills around the call it spills at the call site, where every lane of the wave is active.
+template <int NV> struct TeamVals { double v[NV]; double s; int idx[NV]; bool valid[NV]; bool ok; };
+template <int NV>
+__device__ __attribute__((noinline)) TeamVals<NV> team_sum_call(unsigned long long* words, int M, int member, unsigned seq, unsigned* err, unsigned spin_limit, int lane,
+                                                                TeamVals<NV> x)
+{
+    x.ok = team_sum<NV>(words, M, member, seq, err, spin_limit, lane, x.idx, x.valid, x.v, x.s);
+    return x;
+}
 
 // Optional phase timers (build with -DPMF_TIMING): per-wave shader-clock totals of the phases of row_eval,
 // added to a global array at kernel exit.  Slots: 0 gather, 1 phase 1, 2 coef/div, 3 phase 2, 4 combine, 5 whole kernel.
@@ -203,11 +312,13 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false, bool TM = fa
     int red_sel, red_bytes;   // the set the next combine_waves uses; bytes per set
     int wid;
     int member = 0;                    // TM: this workgroup's place in its giant-row team (0 otherwise)
+    int tm_M = 1;                      // TM: members of the team
     unsigned tm_seq = 0;               // TM: exchanges so far
     unsigned long long* tm_words = nullptr;   // TM: this team's exchange area
     unsigned* tm_err = nullptr;        // TM: != 0: some exchange of this launch timed out, give up
     unsigned tm_spin = TEAM_SPIN_LIMIT;
     static_assert(!TM || NW > 1, "giant-row teams are teams of multi-wave workgroups");
+    static constexpr unsigned TEAM_ROUND = 64;   // a member's share of a row is a whole number of these
     // launch constants
     const T* F;
     int k, ldF, s_load, s_stride, cap, tail;
@@ -694,83 +805,28 @@ template <class T, int NC, int SL = 0, int NW = 1, bool PF = false, bool TM = fa
         double* red_l = (double*)(red_base + red_sel * red_bytes);
         SA* red_slots = (SA*)(red_base + red_sel * red_bytes + 16 * ((NW * sizeof(double) + 15) / 16));   // (the set the NEXT combine writes: nobody reads it now)
         if (wid == 0) {
-            const unsigned long long tag = (unsigned long long)tm_seq << 32;
-            unsigned long long* slots = tm_words + 2 + (size_t)(tm_seq & 1u) * GT_M * GT_GRAN;
-            unsigned long long* mine = slots + (size_t)member * GT_GRAN;
-            const bool carrier = jg == 0;
+            int idx[NC];
+            bool valid[NC];
+            double v[NC];
 #pragma unroll
             for (int s = 0; s < NS; s++) {
 #pragma unroll
                 for (int e = 0; e < SN; e++) {
-                    if (carrier && slot_on[s]) {
-                        const unsigned long long b = __builtin_bit_cast(unsigned long long, (double)(act[s * SN + e] ? tot[s * SN + e] : (T)0));
-                        const int v = slotq[s] * SN + e;
-                        gt_store(mine + 2 * v, (b & 0xffffffffull) | tag);
-                        gt_store(mine + 2 * v + 1, (b >> 32) | tag);
-                    }
+                    idx[s * SN + e] = slotq[s] * SN + e;
+                    valid[s * SN + e] = jg == 0 && slot_on[s];
+                    v[s * SN + e] = (double)(act[s * SN + e] ? tot[s * SN + e] : (T)0);
                 }
             }
-            if (lane == 0) {
-                const unsigned long long b = __builtin_bit_cast(unsigned long long, lsum);
-                gt_store(mine + 2 * (GT_VALS - 1), (b & 0xffffffffull) | tag);
-                gt_store(mine + 2 * (GT_VALS - 1) + 1, (b >> 32) | tag);
-            }
-            T sum[NC];
-            double lt = 0.0;
-#pragma unroll
-            for (int i = 0; i < NC; i++) sum[i] = (T)0;
-            bool dead = false;
-            for (int m = 0; m < GT_M; m++) {
-                T pv[NC];
-                double pl = lsum;
-#pragma unroll
-                for (int i = 0; i < NC; i++) pv[i] = tot[i];
-                if (m != member && !dead) {
-                    const unsigned long long* theirs = slots + (size_t)m * GT_GRAN;
-                    unsigned long long lo[NC], hi[NC], l0 = tag, l1 = tag;
-                    unsigned spins = 0;
-                    for (;;) {
-                        bool ok = true;
-#pragma unroll
-                        for (int s = 0; s < NS; s++) {
-#pragma unroll
-                            for (int e = 0; e < SN; e++) {
-                                const int i = s * SN + e;
-                                lo[i] = tag; hi[i] = tag;
-                                if (carrier && slot_on[s]) {
-                                    const int v = slotq[s] * SN + e;
-                                    lo[i] = gt_load(theirs + 2 * v);
-                                    hi[i] = gt_load(theirs + 2 * v + 1);
-                                }
-                                ok = ok && (lo[i] >> 32) == tm_seq && (hi[i] >> 32) == tm_seq;
-                            }
-                        }
-                        if (lane == 0) { l0 = gt_load(theirs + 2 * (GT_VALS - 1)); l1 = gt_load(theirs + 2 * (GT_VALS - 1) + 1); }
-                        ok = ok && (l0 >> 32) == tm_seq && (l1 >> 32) == tm_seq;
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        if ((++spins & 255u) == 0 && (spins > tm_spin || __hip_atomic_load(tm_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                            if (lane == 0) __hip_atomic_store(tm_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            dead = true;
-                            break;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < NC; i++) pv[i] = (T)__builtin_bit_cast(double, (lo[i] & 0xffffffffull) | (hi[i] << 32));
-                    pl = uniform(__builtin_bit_cast(double, (l0 & 0xffffffffull) | (l1 << 32)));
-                }
-#pragma unroll
-                for (int i = 0; i < NC; i++) sum[i] = m == 0 ? pv[i] : sum[i] + pv[i];
-                lt = m == 0 ? pl : lt + pl;
-            }
-            if (carrier) {
+            double lt = lsum;
+            (void)team_sum<NC>(tm_words, tm_M, member, tm_seq, tm_err, tm_spin, lane, idx, valid, v, lt);
+            if (jg == 0) {
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
                     if (slot_on[s]) {
-                        SA v;
+                        SA w;
 #pragma unroll
-                        for (int e = 0; e < SN; e++) v.v[e] = act[s * SN + e] ? sum[s * SN + e] : (T)0;
-                        red_slots[slotq[s]] = v;
+                        for (int e = 0; e < SN; e++) w.v[e] = act[s * SN + e] ? (T)v[s * SN + e] : (T)0;
+                        red_slots[slotq[s]] = w;
                     }
                 }
             }

@@ -41,9 +41,11 @@ np.save({out!r}, np.stack(outs))
 """
 
 
-def run_child(tmp_path, tag, env, k=100, prec=False, repeat=1, maxupd=1500, w=1.0, niter=2):
+def run_child(tmp_path, tag, env, k=100, prec=False, repeat=1, maxupd=1500, w=1.0, niter=2, lane_teams=False):
     out = str(tmp_path / f"{tag}.npy")
     e = dict(os.environ)
+    if not lane_teams:
+        e["POISMF_HIP_NO_LANE_TEAMS"] = "1"   # (the giant-row tests lower the giant threshold to 256: without this, k = 100 fp64 rows of 385 .. 8192 would be lane teams)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, k=k, prec=prec, repeat=repeat, maxupd=maxupd, w=w, niter=niter)], check=True,
                        env=e, cwd=ROOT, timeout=900, capture_output=True, text=True)
@@ -128,6 +130,51 @@ def test_a_giant_team_that_gives_up_is_rerun_by_one_workgroup_per_row(tmp_path):
         pytest.skip("no giant-row team launches under this knob")
     gave, _, err = run_child(tmp_path, "gave_up", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_TEAM_SPIN_LIMIT": "1"})
     one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_NO_GIANT_TEAMS": "1"})
+    assert "re-run on the streamed path" in err, err
+    assert np.isfinite(gave).all()
+    assert np.array_equal(gave, one)
+
+
+# ---- lane teams: k = 100 fp64 TNCG rows of 385 .. 8192 nonzeros RESIDENT over ceil(class / 384) four-wave workgroups (lane_eval.hpp, TM_) ----------
+def test_lane_team_rows_vs_oracle_repeatable_and_planned(tmp_path):
+    """Default thresholds: the rows of 700 .. 5000 nonzeros take lane teams of 2 .. 11 workgroups (M = ceil(class / 384)), the 9000-nonzero row a giant
+    team, the short ones the resident one-CU instances.  Against the oracle (TNC's own stopping tolerance, see above), three runs the same bits."""
+    res, plan, _ = run_child(tmp_path, "lt", {}, k=100, prec=False, repeat=3, lane_teams=True)
+    if not NO_TEAMS and not os.environ.get("POISMF_HIP_NO_LANE_TEAMS") and not os.environ.get("POISMF_HIP_NO_LANE"):
+        assert "half_sweep_lane_team_kernel<double,tncg,KS=50,V=1,L=0+32,NW=4,M=2>" in plan, plan
+        assert "half_sweep_lane_team_kernel<double,tncg,KS=50,V=1,L=0+32,NW=4,M=11>" in plan, plan
+        assert "half_sweep_giant_kernel<double,tncg,NW=8,M=32" in plan, plan
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[0], res[2])
+    csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, 100, False, seed=33)
+    l2, _, _ = harness.auto_defaults("tncg", 100)
+    args = dict(l2_reg=l2, l1_reg=0.0, w_mult=1.0, step_size=1e-7, limit_step=True, niter=2, maxupd=1500, early_stop=True, reuse_prev=False)
+    Ar, Br = oracle_run(False, csr, csc, A0, B0, "tncg", args)
+    nA = A0.size
+    A, B = res[0][:nA].reshape(A0.shape), res[0][nA:].reshape(B0.shape)
+    assert np.isfinite(A).all() and A.min() >= 0 and not A[-1].any()
+    og = harness.poisson_objective(A, B, csr, l2, 0.0, 1.0)
+    orf = harness.poisson_objective(Ar, Br, csr, l2, 0.0, 1.0)
+    print(f"lane teams k=100: objective gpu {og:.10g} checker {orf:.10g} rel {abs(og - orf) / abs(orf):.3g}")
+    assert abs(og - orf) <= 5e-4 * abs(orf)
+
+
+def test_lane_team_sums_match_the_streamed_path(tmp_path):
+    """two evaluations per row (gradient + one trial): resident teams against the eight-wave streamed kernel (POISMF_HIP_NO_LANE_TEAMS=1) -- the same
+    sums in another order, equal to rounding; with weights the per-row constant term crosses the team too"""
+    for w in (1.0, 3.0):
+        team, _, _ = run_child(tmp_path, f"lt{w}", {}, k=100, maxupd=2, niter=1, w=w, lane_teams=True)
+        one, _, _ = run_child(tmp_path, f"st{w}", {"POISMF_HIP_NO_LANE_TEAMS": "1"}, k=100, maxupd=2, niter=1, w=w)
+        err = H.scaled_err(team[0], one[0])
+        print(f"lane teams vs streamed, w={w}, two evaluations: scaled error {err:.3g}")
+        assert np.isfinite(team).all() and team[0].any()
+        assert err <= 1e-12
+
+
+def test_a_lane_team_that_gives_up_is_rerun_on_the_streamed_kernel(tmp_path):
+    if NO_TEAMS or os.environ.get("POISMF_HIP_NO_LANE_TEAMS") or os.environ.get("POISMF_HIP_NO_LANE"):
+        pytest.skip("no lane-team launches under this knob")
+    gave, _, err = run_child(tmp_path, "gave_up", {"POISMF_HIP_TEAM_SPIN_LIMIT": "1"}, k=100, lane_teams=True)
+    one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_NO_LANE_TEAMS": "1", "POISMF_HIP_NO_GIANT_TEAMS": "1"}, k=100)
     assert "re-run on the streamed path" in err, err
     assert np.isfinite(gave).all()
     assert np.array_equal(gave, one)
