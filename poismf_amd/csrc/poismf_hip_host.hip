@@ -1245,7 +1245,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // teams in the half, the giant rows' launch stays on the main stream, in front of them)
     bool any_lane_team = false;
     for (const Launch& L : launches) any_lane_team = any_lane_team || (L.team > 1 && L.lane_L > 0);
-    hipStream_t long_stream = (forked && !any_lane_team) ? s->aux_stream : s->stream;
+    // POISMF_HIP_LANE_TEAM_STREAM=1 (tuning knob): giant rows and lane teams one after the other on the SECOND stream, beside the main stream's non-team bins
+    static const int lt_stream = getenv("POISMF_HIP_LANE_TEAM_STREAM") ? atoi(getenv("POISMF_HIP_LANE_TEAM_STREAM")) : 1;
+    const bool teams_on_main = any_lane_team && lt_stream == 0;
+    hipStream_t long_stream = (forked && !teams_on_main) ? s->aux_stream : s->stream;
     double queued[2] = { 0.0, 0.0 };
     // The long rows go to the second stream to run NEXT TO the other bins, not after them.  The other bins' kernels are persistent
     // (a workgroup keeps its CU until the bin's queue is empty): whichever kernel reaches the chip first fills it, and on config C5
@@ -1254,7 +1257,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // that count (a one-wave gate kernel with a time limit, above; rounds 3-4a: hipStreamWaitValue32) before it launches anything else.
     // Arrivals only ever grow, so a chip that cannot hold the whole launch at once delays the main stream by the gate's 2 ms, no more.
     static const bool no_arrive = getenv("POISMF_HIP_NO_ARRIVE_WAIT") != nullptr;   // testing knob
-    const bool hold_back = forked && any_long && !no_arrive && !any_lane_team;
+    const bool hold_back = forked && any_long && !no_arrive && !teams_on_main;
     if (hold_back) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, sizeof(unsigned), s->stream));
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
@@ -1304,7 +1307,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         a.team_members = (unsigned)std::max(1, L.team);
         // (a giant-row team launch and everything that brackets it -- the copy of its rows, their restoration and re-run -- lives on the stream
         // the long rows run on)
-        hipStream_t tst = giant ? long_stream : s->stream;
+        hipStream_t tst = (giant || (lane_team && !teams_on_main)) ? long_stream : s->stream;
         if (L.team > 1) {
             if (a.queue == nullptr) {            // teams always draw their rows from a queue
                 a.queue = s->d_queue + MAX_LAUNCHES + (launch_no % 8);
@@ -1375,7 +1378,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.lane_A = L.lane_A; o.lane_LL = L.lane_LL; o.lane_small = L.lane_small; o.lane_LP = L.lane_LP; o.lane_tx = L.lane_tx; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
             static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
             o.generic_only = generic_only;
-            o.main_stream = s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
+            o.main_stream = lane_team ? tst : s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
             o.lds = lds; o.grid = grid; o.grid_mult = grid_mult;
             o.device = s->device; o.num_cu = s->num_cu;
             // profiling sessions: events around this launch, on the stream it goes to (launch_one_here's choice)
