@@ -858,6 +858,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // lane collects) -- two selects and an add on the VALU (6 cycles) where v_permlane32_swap + add cost 12 (the swap alone ~10,
     // scripts/probes/valu_probe.hip); its latency is the other wave's issue time at two waves per SIMD.  The same sum, the same
     // bits.  Doubles (one wave per SIMD, nothing to hide a round trip behind) keep the swaps.
+#ifndef PMF_LANE_PK
+#define PMF_LANE_PK 1   // floats: packed multiply-adds (v_pk_fma_f32) in the transposing butterfly's chains
+#endif
+// (the dots packed the same way -- two partial sums per set, another order -- measured: TNCG fp32 110.8 -> 109.9 ms, CG fp32 18.3 -> 18.0; not kept)
 #ifndef PMF_LANE_BPERM32
 #define PMF_LANE_BPERM32 0   // measured: PG item rows 4.86 -> 5.19 ms, C2 CG fp32 2.20 -> 2.97, TNCG fp32 12.6 -> 17.2: the round trip sits in every dependent chain of the reduction
 #endif
@@ -909,6 +913,31 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                         constexpr int h = decltype(hc)::value;
                         T u[8];
                         // chain j: dimension 16 b + 4 h + j / 2 + 8 (j % 2)   (the two inputs of fold 4 h + j / 2)
+                        if constexpr (sizeof(T) == 4 && PMF_LANE_PK && N % 2 == 0 && LV >= 2) {   // (one set: the lone multiply is contracted with the fold's add by the compiler -- kept as it is, bit for bit)
+                            // floats: the chains of two NEIGHBOURING dimensions in one v_pk_fma_f32 (the tile's elements C, C + 1 sit in neighbouring
+                            // registers: they arrive four to a 16-byte load) -- the same multiply-adds in the same order, half the instructions
+                            typedef float v2f __attribute__((ext_vector_type(2)));
+                            v2f u2[4];
+                            static_for<0, LV>([&](auto sc) {
+                                constexpr int s_ = decltype(sc)::value;
+                                static_for<0, 4>([&](auto pc) {
+                                    constexpr int p = decltype(pc)::value;
+                                    constexpr int d = 4 * h + 2 * (p % 2) + 8 * (p / 2);      // pair p: dimensions d, d + 1 = chains j0, j0 + 2, j0 = 4 (p % 2) + p / 2
+                                    if constexpr (d < N) {
+                                        constexpr int C = 16 * b + d;
+                                        const v2f tt = { (float)t[s_][C], (float)t[s_][C + 1] };
+                                        const v2f cc = { (float)coef[s_], (float)coef[s_] };
+                                        if constexpr (s_ == 0) u2[p] = cc * tt;
+                                        else u2[p] = __builtin_elementwise_fma(cc, tt, u2[p]);
+                                    }
+                                });
+                            });
+                            static_for<0, 4>([&](auto pc) {
+                                constexpr int p = decltype(pc)::value;
+                                constexpr int d = 4 * h + 2 * (p % 2) + 8 * (p / 2);
+                                if constexpr (d < N) { u[4 * (p % 2) + p / 2] = (T)u2[p].x; u[4 * (p % 2) + p / 2 + 2] = (T)u2[p].y; }
+                            });
+                        } else
                         static_for<0, LV>([&](auto sc) {
                             constexpr int s_ = decltype(sc)::value;
                             static_for<0, 8>([&](auto jc) {
