@@ -861,7 +861,12 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #ifndef PMF_LANE_PK
 #define PMF_LANE_PK 1   // floats: packed multiply-adds (v_pk_fma_f32) in the transposing butterfly's chains
 #endif
-// (the dots packed the same way -- two partial sums per set, another order -- measured: TNCG fp32 110.8 -> 109.9 ms, CG fp32 18.3 -> 18.0; not kept)
+#ifndef PMF_LANE_PK_DOTS
+#define PMF_LANE_PK_DOTS 1   // floats, the instances whose dots take the point as scalar operands (four sets and more): dimensions c, c + 1 in one v_pk_fma_f32 with
+                             // an SGPR pair -- TWO partial sums per set (even and odd dimensions, added at the end), as the register engine's lane_dot has
+                             // always done (reg_eval.hpp): PG(10) item rows 3.45 -> 3.15 ms.  (The instances of fewer sets read the point from LDS: packed there
+                             // too, TNCG fp32 110.8 -> 109.9 ms, CG fp32 18.3 -> 18.0 for another order of their sums -- not kept.)
+#endif
 #ifndef PMF_LANE_BPERM32
 #define PMF_LANE_BPERM32 0   // measured: PG item rows 4.86 -> 5.19 ms, C2 CG fp32 2.20 -> 2.97, TNCG fp32 12.6 -> 17.2: the round trip sits in every dependent chain of the reduction
 #endif
@@ -1165,6 +1170,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             // dimension c of the point sits in lane (c % CW) + 16 (c / CW) (XPOSE: in lane c): one v_readlane, then a scalar operand of LT multiply-adds
             // (read in groups of GS ahead of their use: a v_readlane's SGPR needs two wait states before a VALU may read it)
             constexpr int GS = 4;
+            constexpr bool PKD = sizeof(T) == 4 && PMF_LANE_PK_DOTS && KP % GS == 0;
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f pred2[LT];   // PKD: even / odd dimensions' partial dot products, two multiply-adds per v_pk_fma_f32
             static_for<0, (KP + GS - 1) / GS>([&](auto gc) {
                 constexpr int c0 = decltype(gc)::value * GS;
                 T ac[GS];
@@ -1175,6 +1183,18 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                         asm volatile("" : "+s"(ac[c - c0]));   // here, not sunk next to its use
                     }
                 });
+                if constexpr (PKD) {
+                    static_for<0, GS / 2>([&](auto hc) {
+                        constexpr int c = c0 + 2 * decltype(hc)::value;
+                        const v2f a2 = { (float)ac[c - c0], (float)ac[c - c0 + 1] };
+                        static_for<0, LT>([&](auto sc) {
+                            constexpr int s2 = decltype(sc)::value;
+                            const v2f t2 = { (float)t[s2][c], (float)t[s2][c + 1] };
+                            if constexpr (c == 0) pred2[s2] = t2 * a2;
+                            else pred2[s2] = __builtin_elementwise_fma(t2, a2, pred2[s2]);
+                        });
+                    });
+                } else
                 static_for<0, GS>([&](auto ic) {
                     constexpr int c = c0 + decltype(ic)::value;
                     if constexpr (c < KP) {
@@ -1186,6 +1206,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                     }
                 });
             });
+            if constexpr (PKD) {
+#pragma unroll
+                for (int s2 = 0; s2 < LT; s2++) pred[s2] = (T)(pred2[s2].x + pred2[s2].y);
+            }
         } else if constexpr (TX > 0) {
             // TX: lane j's own row of the LDS image against the point (a broadcast read), slots in groups of GQ, the next group requested
             // before the current group's multiply-adds; the plain left-to-right chain of KP multiply-adds of the other instances
