@@ -343,8 +343,29 @@ __device__ __forceinline__ void team_rows(const HalfArgs<T>& a, EV& ev, unsigned
     ev.tm_words = a.team_buf + GT_HEAD_WORDS + (size_t)team * gt_team_words(M);
     ev.tm_err = a.team_err;
     ev.tm_spin = a.team_spin;
-    unsigned long long* mail = ev.tm_words;   // [2]: { row number << 32 | ticket } of the row with that parity
+    unsigned long long* mail = ev.tm_words;   // [2]: { row number << 32 | ticket } of the row with that parity; [2]: members that have arrived
     constexpr unsigned END = 0xffffffffu;
+    // Nobody draws a row before the whole team is on the chip: behind the other bins' persistent workgroups (second stream, §4.8) a team's members can
+    // arrive tens of milliseconds apart -- longer on bigger problems -- and an exchange waiting for a partner that has no CU yet would run into the
+    // exchange's time-out.  The wait for arrivals is patient (64 x that limit) and ends at once when the launch has no rows left.
+    if (threadIdx.x == 0) atomicAdd((unsigned*)(mail + 2), 1u);
+    // (POISMF_HIP_TEAM_SPIN_LIMIT=1, the tests' way to a launch that gives up: it gives up HERE, always -- with a limit of one poll a fast leader's
+    // ticket could still arrive in time, and a launch in which nobody happened to wait too long kept its team results: 5 of 12 runs under
+    // POISMF_HIP_NO_ROW_INTERRUPT=1, whose tickets are a host-memory read faster)
+    if (a.team_spin <= 1u && threadIdx.x == 0) __hip_atomic_store(a.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ev.wid == 0) {
+        for (unsigned spins = 0;; spins++) {
+            if (a.team_spin <= 1u) break;
+            if (uniform((unsigned)gt_load(mail + 2)) >= M) break;
+            if ((spins & 255u) == 255u) {
+                if (uniform(__hip_atomic_load(a.team_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+                if (uniform(__hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= a.nrows) break;
+            }
+            if ((spins >> 6) > a.team_spin) { __hip_atomic_store(a.team_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
     for (unsigned rowno = 1;; rowno++) {
         // (all 64 lanes of the first wave poll and post: no lane-divergent region around the waits -- row_eval.hpp, team_sum, on why)
         if (ev.wid == 0) {

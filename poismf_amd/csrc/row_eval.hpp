@@ -62,7 +62,8 @@ constexpr unsigned TEAM_SPIN_LIMIT = 1u << 20;   // polls (~1 us each) before a 
 // ceil(nnz / GT_M) rounded up to whole 64s, through its eight waves exactly as a single workgroup streams a whole row; per
 // evaluation the members' partial gradients and log-likelihood sums cross CUs as tagged 8-byte granules (as the register teams'
 // do) and are added in member order, so every wave of every member keeps the same bits and takes the same branches.
-// Buffer (8-byte words): [0] arrival counter, then per team { mailbox[2], exchange[2 parities][GT_M members][GT_GRAN granules] }.
+// Buffer (8-byte words): a header line ([0]: arrival counter), then per team { a line with mailbox[2], exchange[2 parities][members][GT_GRAN words] };
+// a member's GT_GRAN words are whole 128-byte lines: its values' granules, the scalar's, and pad granules (team_sum).
 constexpr int GT_M = 32;                           // members of a giant-row team (a function of nothing: a row's arithmetic must not depend on its launch)
 constexpr int GT_VALS = 258;                       // doubles per exchange: a k-vector of up to 256 elements (k <= 256 fp64 / 512 fp32: two exchanges' worth is never needed) + the sum
 constexpr unsigned GT_PAD_AT = 2 * GT_VALS;          // first of a member's pad granules: where lanes that carry no value of their own publish (team_sum)
