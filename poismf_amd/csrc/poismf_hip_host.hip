@@ -636,7 +636,10 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
         fprintf(stderr, "poismf_hip: k = %zu is outside the supported range (1..%d)\n", k, 128 * SLOT_ELEMS);
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    if (const hipError_t e = hipSetDevice(device); e != hipSuccess) {   // no device, wrong index: rc 1, and stderr says it was not memory
+        pmf_last_hip_error() = e;
+        return nullptr;
+    }
     poismf_hip_session* s = new (std::nothrow) poismf_hip_session();
     if (!s) return nullptr;
     s->device = device;
