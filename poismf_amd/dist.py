@@ -213,10 +213,38 @@ class ShardedAlternation:
         self.multi = dist.is_initialized() and dist.get_world_size(group) > 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stopped = [False, False]  # [B, A]
+        self._timed = None  # measurement only (bench.py): [(what, start event, end event)] of every exchange while switched on
+
+    def time_exchanges(self, on=True):
+        """Bracket every exchange with device events on the stream it is issued on (a profiled pass of bench.py; off in the product path)."""
+        self._timed = [] if on else None
+
+    def exchange_ms(self):
+        """{"rows": ms, "colsum_partials": ms, "calls": n} of the exchanges since time_exchanges(True): device time between each exchange's
+        two events (on its own stream: what the transfer occupies, whether or not compute on the other stream hides it)."""
+        out = {"rows": 0.0, "colsum_partials": 0.0, "calls": 0}
+        for what, e0, e1 in self._timed or []:
+            e1.synchronize()
+            out[what] += e0.elapsed_time(e1)
+            out["calls"] += 1
+        return out
+
+    @contextlib.contextmanager
+    def _bracket(self, what, tensor):
+        if self._timed is None or not tensor.is_cuda:
+            yield
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        yield
+        e1.record()
+        self._timed.append((what, e0, e1))
 
     def _exchange(self, which, j, nseg):
         parts = [segment_of(r, j, nseg) for r in self.ranges[which]]
-        exchange_shards(self.be.factor(which), parts, self.rank, self.group)
+        full = self.be.factor(which)
+        with self._bracket("rows", full):
+            exchange_shards(full, parts, self.rank, self.group)
 
     def _shared_colsum(self, which, ctx):
         """Each rank computes its share of the blocks of the fixed factor's column sums, the partials are all-gathered (in the
@@ -229,7 +257,9 @@ class ShardedAlternation:
         parts = equal_ranges(nb, world)
         be.colsum_partial(which, *parts[self.rank])
         with (ctx() if ctx is not None else contextlib.nullcontext()):
-            exchange_shards(be.partials(which), parts, self.rank, self.group)
+            part = be.partials(which)
+            with self._bracket("colsum_partials", part):
+                exchange_shards(part, parts, self.rank, self.group)
         be.partials_ready()
 
     def _half(self, which, cnst_div):

@@ -67,3 +67,33 @@ def test_main_prints_the_compact_line_last():
     src = open(os.path.join(ROOT, "bench.py")).read()
     tail = src[src.rindex("write_full(final_line)"):]
     assert "compact_line(final_line)" in tail and tail.count("print(") == 1
+
+
+def test_compact_line_of_a_multi_gpu_object_carries_what_the_communicator_said():
+    b = _bench()
+    full = dict(_recorded())
+    full["n_gpus"] = 8
+    full["comm"] = {"backend": "nccl", "comm_ranks": 8, "rccl_ranks": 8, "rccl_version": "2.22.3",
+                    "per_rank_nnz": {"A_half_csr": [12493725] * 8, "B_half_csc": [12493725] * 8},
+                    "exchange": {"rows_ms_per_sweep": 0.4321987, "colsum_partials_ms_per_sweep": 0.0123456, "exchanges_per_sweep": 7}}
+    line = json.dumps(b.compact_line(full), separators=(",", ":"))
+    assert len(line) < 2000, len(line)
+    back = json.loads(line)
+    assert back["rccl_ranks"] == 8 and back["comm"]["ranks"] == 8 and back["comm"]["backend"] == "nccl"
+    assert len(back["comm"]["nnz_per_rank"]) == 8 and back["comm"]["exchange_ms"] == 0.4322
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_returns_their_exit_code():
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset launches the ranks itself (no GPU here: every rank stops with the "needs an
+    MI355X" message, the launcher fails, and the parent hands that exit code on instead of a JSON line)"""
+    import subprocess
+    import sys
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    out = res.stdout + res.stderr
+    import torch
+    if torch.cuda.is_available():
+        return   # (on a GPU box the real run is tests/test_gpu_dist2.py's)
+    assert res.returncode != 0
+    assert "needs an MI355X" in out and "launch with torch.distributed.run" not in out

@@ -38,3 +38,23 @@ def test_two_processes_reproduce_the_single_process_result(method, prec, early, 
     assert np.array_equal(np.isfinite(got["A"]), np.isfinite(A))
     fa, fb = np.isfinite(A), np.isfinite(B)
     assert np.array_equal(got["A"][fa], A[fa]) and np.array_equal(got["B"][fb], B[fb])
+
+
+def test_bench_gpus_2_launches_itself_and_prints_one_parseable_line():
+    """`python3 bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): the parent starts two fresh ranks before any GPU call,
+    relays rank 0's compact line as its LAST stdout line and returns the ranks' exit code.  Two ranks on the one GPU of the test box
+    (POISMF_BENCH_SHARE_GPUS=1, gloo: RCCL refuses two ranks on one device), the metric's matrix shrunk 10 x."""
+    import json
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(POISMF_BENCH_SHARE_GPUS="1", POISMF_BENCH_BACKEND="gloo", POISMF_BENCH_SCALE="10", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    last = res.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "strong"
+    assert line["comm"]["ranks"] == 2 and line["comm"]["backend"] == "gloo" and line["rccl_ranks"] is None   # (gloo here; nccl reports RCCL's count)
+    nnz = line["comm"]["nnz_per_rank"]
+    assert len(nnz) == 2 and abs(sum(nnz) * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"]) / line["value"] - 1) < 1e-3
+    assert line["comm"]["exchange_ms"] > 0
+    assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line   # (the CPU leg is rank 0 at N = 1 only)
