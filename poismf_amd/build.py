@@ -164,8 +164,27 @@ def _build_locked(force, verbose):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
+            isa_guard(out)           # (before the library is marked as built: a violated invariant leaves it stale)
             _mark(out, digest)
     return lib_path(False), lib_path(True)
+
+
+def isa_guard(lib):
+    """scripts/isa_guard.py on a freshly linked library: the lane-team kernels must reach their cross-CU exchange through a call of the
+    out-of-line team_sum_call, and that function must not spill while EXEC may be narrowed (DESIGN.md 4.8).  Raises on a violation;
+    says so and goes on where llvm-objdump is missing.  POISMF_HIP_NO_ISA_GUARD=1 skips it (development builds of variants)."""
+    if os.environ.get("POISMF_HIP_NO_ISA_GUARD") or "-DPMF_LANE_ONLY" in os.environ.get("POISMF_HIP_EXTRA_FLAGS", ""):
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmf_isa_guard", os.path.join(os.path.dirname(HERE), "scripts", "isa_guard.py"))
+    guard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(guard)
+    if not os.path.exists(guard.OBJDUMP):
+        print(f"poismf_amd.build: no {guard.OBJDUMP}: ISA guard skipped for {os.path.basename(lib)}", file=sys.stderr)
+        return
+    lines = []
+    if not guard.check_library(lib, lines.append):
+        raise RuntimeError("ISA guard violated in " + lib + ":\n" + "\n".join(l for l in lines if ": info: " not in l))
 
 
 if __name__ == "__main__":

@@ -137,7 +137,13 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr int LP = LP_;                                                  // nonzeros of the partial LDS set (0: none)
     static constexpr int LLT = LL_ + (LP_ > 0 ? 1 : 0);                              // sets read from LDS (the partial one last)
     static constexpr int LV = LV_, LA = LA_, LL = LL_, LR = LV_ + LA_, LT = LV_ + LA_ + LLT;   // sets: VGPR, AGPR, LDS
-    static_assert(LP_ == 0 || ((LP_ & (LP_ - 1)) == 0 && LP_ < WAVE), "a partial set: a power of two of nonzeros, the last set of the wave");
+    static_assert(LP_ == 0 || (LP_ < WAVE && ((LP_ & (LP_ - 1)) == 0 || 2 * LP_ >= WAVE)), "a partial set: fewer nonzeros than lanes, the last set of the wave");
+    // the row of the partial set's image that lane l reads: its own below LP, an earlier lane's (finite data, coefficient 0) from there on
+    static __device__ __forceinline__ int part_row(int l)
+    {
+        if constexpr (LP_ > 0 && (LP_ & (LP_ - 1)) == 0) return l & (LP_ - 1);
+        else return l < LP_ ? l : l - LP_;   // (LP_ >= 32: l - LP_ < LP_)
+    }
     static constexpr int L = LT, NW = NW_, M = 1;
     static constexpr int W = KS < 13 ? KS : 13;           // slots per staged chunk (row stride of the LDS image: 13 slots = 52 banks, conflict-free b128 reads)
     static constexpr int NCH = (KS + W - 1) / W;          // chunks per factor row; chunk c starts at slot min(c W, KS - W)
@@ -191,7 +197,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // Image: slot-column q (dimensions 4 q .. 4 q + 3) of lane l at slot XP_QS q + l + l / 16 -- one pad slot per 16 lanes and a
     // column stride = 4 (mod 16) make both the writes (a lane's own slot) and the reads (lane 4 q + p reads lanes 16 p .. 16 p + 15 of
     // column q: the 16 lanes of a ds_read_b128 service group hit 16 different bank quads) conflict-free.
-    static constexpr bool XPOSE = PMF_LANE_XPOSE && sizeof(T) == 4 && LL_ == 0 && LP_ == 0 && (KP + WAVE - 1) / WAVE == 1;
+    // (round 6: a PARTIAL LDS set may ride along -- LP_ > 0: its slots are read from LDS in the dots and in the butterfly's chains, everything else as without)
+    static constexpr bool XPOSE = PMF_LANE_XPOSE && sizeof(T) == 4 && LL_ == 0 && (KP + WAVE - 1) / WAVE == 1;
     static constexpr int XP_QS = 68;
 #ifndef PMF_LANE_COAL
 #define PMF_LANE_COAL 1
@@ -244,7 +251,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #endif
     // (only where four or more sets share each v_readlane: with the one to three sets of the CG / TNCG instances the 52 readlanes of an
     // evaluation cost more than 13 broadcast reads -- C2 CG fp32 2.20 -> 2.58 ms, TNCG fp32 12.6 -> 13.5 with it)
-    static constexpr bool SPOINT = PMF_LANE_SPOINT && sizeof(T) == 4 && NC == 1 && LLT == 0 && LV_ >= 4;
+    static constexpr bool SPOINT = PMF_LANE_SPOINT && sizeof(T) == 4 && NC == 1 && LL_ == 0 && LV_ >= 4;   // (LP_ > 0: the partial set's slots come from LDS, the point stays scalar)
 #ifndef PMF_LANE_PIPE_MW
 #define PMF_LANE_PIPE_MW 2   // sweep_rows' cross-row software pipeline (tickets two rows ahead, indices one) for MULTI-WAVE rows of this engine:
                              // 0 = never, 1 = always (rounds 3-4a), 2 = under PG only.  Measured on the C4 matrix (variant builds, same box):
@@ -649,6 +656,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 wave_lds_fence();
                 own_rows_of_image(sc);
             };
+            if constexpr (LP > 0) request_lds_sets();   // (its DMA is in flight under the register sets' loads)
             static_for<0, LV>(request_set);
             static_for<0, LV>(through_image);
         } else if constexpr (TX > 0) {
@@ -746,7 +754,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         if constexpr (ALIAS) { __builtin_amdgcn_s_waitcnt(0xc07f); wave_lds_fence(); }   // the scratch of the reductions is this buffer
         // LDS sets: their chunks stay in the buffers (set u, chunk c in buffer u NCH + c)
         if constexpr (LL > 0 || LP > 0) {
-            if constexpr (!(TEMP_A && LL > 0)) request_lds_sets();
+            if constexpr (!(TEMP_A && LL > 0) && !(COAL && LP > 0)) request_lds_sets();
             wait_dma<0>();
         }
     }
@@ -805,7 +813,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         } else {
             constexpr int c = slot_chunk(Q);
             if constexpr (S - LR < LL) v = *((const SA*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + lane * W + (Q - chunk_start(c)));
-            else v = *((const SA*)(part + c * PART_BYTES) + (lane & (LP - 1)) * W + (Q - chunk_start(c)));   // (lanes >= LP: some row's finite data, coefficient 0)
+            else v = *((const SA*)(part + c * PART_BYTES) + part_row(lane) * W + (Q - chunk_start(c)));   // (lanes >= LP: some row's finite data, coefficient 0)
         }
         return v;
     }
@@ -817,7 +825,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         else {
             constexpr int q = C / SN, c = slot_chunk(q);
             if constexpr (S - LR < LL) return *((const T*)(stage + ((S - LR) * NCH + c) * STAGE_BYTES) + (lane * W + (q - chunk_start(c))) * SN + C % SN);
-            else return *((const T*)(part + c * PART_BYTES) + ((lane & (LP - 1)) * W + (q - chunk_start(c))) * SN + C % SN);
+            else return *((const T*)(part + c * PART_BYTES) + (part_row(lane) * W + (q - chunk_start(c))) * SN + C % SN);
         }
     }
 
@@ -918,6 +926,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                         constexpr int h = decltype(hc)::value;
                         T u[8];
                         // chain j: dimension 16 b + 4 h + j / 2 + 8 (j % 2)   (the two inputs of fold 4 h + j / 2)
+                        static_assert(LLT == 0 || (sizeof(T) == 4 && PMF_LANE_PK && N % 4 == 0 && LV >= 2 && LV == LR), "a partial LDS set rides in the packed chains only");
                         if constexpr (sizeof(T) == 4 && PMF_LANE_PK && N % 2 == 0 && LV >= 2) {   // (one set: the lone multiply is contracted with the fold's add by the compiler -- kept as it is, bit for bit)
                             // floats: the chains of two NEIGHBOURING dimensions in one v_pk_fma_f32 (the tile's elements C, C + 1 sit in neighbouring
                             // registers: they arrive four to a 16-byte load) -- the same multiply-adds in the same order, half the instructions
@@ -937,6 +946,18 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                                     }
                                 });
                             });
+                            if constexpr (LLT > 0) {
+                                // the partial LDS set's elements of these dimensions: slots 4 b + h (pairs 0, 1) and 4 b + h + 2 (pairs 2, 3), last in every chain
+                                static_for<0, 2>([&](auto gc2) {
+                                    constexpr int g2 = decltype(gc2)::value;
+                                    if constexpr (4 * h + 8 * g2 < N) {
+                                        const SA ls = tile_slot<LR, 4 * b + h + 2 * g2>();
+                                        const v2f cc = { (float)coef[LR], (float)coef[LR] };
+                                        u2[2 * g2] = __builtin_elementwise_fma(cc, v2f{ (float)ls.v[0], (float)ls.v[1] }, u2[2 * g2]);
+                                        u2[2 * g2 + 1] = __builtin_elementwise_fma(cc, v2f{ (float)ls.v[2], (float)ls.v[3] }, u2[2 * g2 + 1]);
+                                    }
+                                });
+                            }
                             static_for<0, 4>([&](auto pc) {
                                 constexpr int p = decltype(pc)::value;
                                 constexpr int d = 4 * h + 2 * (p % 2) + 8 * (p / 2);
@@ -1173,8 +1194,12 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             constexpr bool PKD = sizeof(T) == 4 && PMF_LANE_PK_DOTS && KP % GS == 0;
             typedef float v2f __attribute__((ext_vector_type(2)));
             v2f pred2[LT];   // PKD: even / odd dimensions' partial dot products, two multiply-adds per v_pk_fma_f32
+            static_assert(LLT == 0 || (PKD && GS == SN && LV == LR), "a partial LDS set under scalar-operand dots: one 16-byte slot per group of dimensions");
+            SA pslot[2];     // the partial LDS set's slot of this group of dimensions and of the next (requested one group ahead)
+            if constexpr (LLT > 0) pslot[0] = tile_slot<LR, 0>();
             static_for<0, (KP + GS - 1) / GS>([&](auto gc) {
                 constexpr int c0 = decltype(gc)::value * GS;
+                if constexpr (LLT > 0 && c0 / GS + 1 < KS) pslot[(c0 / GS + 1) & 1] = tile_slot<LR, c0 / GS + 1>();
                 T ac[GS];
                 static_for<0, GS>([&](auto ic) {
                     constexpr int c = c0 + decltype(ic)::value;
@@ -1189,7 +1214,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                         const v2f a2 = { (float)ac[c - c0], (float)ac[c - c0 + 1] };
                         static_for<0, LT>([&](auto sc) {
                             constexpr int s2 = decltype(sc)::value;
-                            const v2f t2 = { (float)t[s2][c], (float)t[s2][c + 1] };
+                            v2f t2;
+                            if constexpr (s2 < LV) t2 = v2f{ (float)t[s2][c], (float)t[s2][c + 1] };
+                            else t2 = v2f{ (float)pslot[(c0 / GS) & 1].v[c - c0], (float)pslot[(c0 / GS) & 1].v[c - c0 + 1] };
                             if constexpr (c == 0) pred2[s2] = t2 * a2;
                             else pred2[s2] = __builtin_elementwise_fma(t2, a2, pred2[s2]);
                         });
@@ -1198,7 +1225,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 static_for<0, GS>([&](auto ic) {
                     constexpr int c = c0 + decltype(ic)::value;
                     if constexpr (c < KP) {
-                        static_for<0, LT>([&](auto sc) {
+                        static_for<0, LV>([&](auto sc) {
                             constexpr int s2 = decltype(sc)::value;
                             if constexpr (c == 0) pred[s2] = t[s2][c] * ac[c - c0];
                             else pred[s2] = fma_t(t[s2][c], ac[c - c0], pred[s2]);

@@ -205,7 +205,12 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
             // instead of the 36 KB of a full LDS set: eight rows per CU, two waves per SIMD (POISMF_HIP_K50_P32=0: off)
             static const bool k50_p32 = getenv("POISMF_HIP_K50_P32") == nullptr || atoi(getenv("POISMF_HIP_K50_P32")) != 0;
             if (cls <= 96 && k50_p32 && method != POISMF_TNCG) return { 1, 0, 0, 1, 1, 32 };
-            if (cls <= 128) return PMF_LANE_A2 ? LaneShape{ 1, 0, 0, 2, 1 } : LaneShape{ 1, 0, 1, 1, 0 };
+            // 97 .. 112 nonzeros (round 6; half of C3's user rows: Poisson(100)): the partial set with 48 nonzeros -- 26 KB of LDS per row, SIX rows per
+            // CU (two SIMDs take two waves) where the full LDS set's 36 KB allow four (POISMF_HIP_K50_P48=0: off)
+            static const bool k50_p48 = getenv("POISMF_HIP_K50_P48") == nullptr || atoi(getenv("POISMF_HIP_K50_P48")) != 0;
+            if (cls <= 112 && k50_p32 && k50_p48 && method != POISMF_TNCG) return { 1, 0, 0, 1, 1, 48 };
+            static const int k50_mid = getenv("POISMF_HIP_K50_MID") ? atoi(getenv("POISMF_HIP_K50_MID")) : (PMF_LANE_A2 ? 2 : 1);   // experiment knob (round 6)
+            if (cls <= 128) return k50_mid == 2 ? LaneShape{ 1, 0, 0, 2, 1 } : LaneShape{ 1, 0, 1, 1, 0 };
             if (cls <= 256) return { 1, 2, 1, 1, 0 };
             if (cls <= 512) return { 1, 2, 1, 2, 0 };
             if (cls <= 1024) return { 1, 2, 1, 4, 0 };
@@ -248,6 +253,11 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
 #define PMF_LANE_PG32X4 1   // rows of 513 .. 1024 nonzeros on FOUR waves of four sets each (three in registers, one in LDS), two such rows per CU
 #endif
             if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1 };
+            // 1025 .. 1088 nonzeros (round 6; 98.6 % of the C4 matrix's item rows above 1024: Poisson(1000)): the same four waves of four register sets
+            // + a PARTIAL LDS set of 16 nonzeros per wave (4 KB; 76 KB of LDS per row: still two rows per CU) instead of the register engine's
+            // eight-wave kernel at one row per CU (0.32 of the byte roofline, the worst bucket of the headline).  POISMF_HIP_PG_P16=0: off
+            static const bool pg_p16 = getenv("POISMF_HIP_PG_P16") == nullptr || atoi(getenv("POISMF_HIP_PG_P16")) != 0;
+            if (PMF_LANE_PG32X4 && pg_p16 && cls > 1024 && cls <= 1088) return { 4, 0, 0, 4, 1, 16 };
             // (1025 .. 1152 nonzeros: 4.5 sets per wave do not fit; six waves x three sets, one row per CU, measured 2.50 ms against 1.85 ms
             // for reg_eval.hpp's eight-wave kernel on the 21 k such rows of the C4 matrix -- they stay there)
             if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };

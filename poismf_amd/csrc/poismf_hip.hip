@@ -840,7 +840,10 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
                 case 12140: return launch_lane<METHOD, 25, 1, 2, 1, 4>(stream, a, grid_mult);
                 case 112140: return launch_lane<METHOD, 25, 1, 2, 1, 4, false, false, 16>(stream, a, grid_mult);
                 case 110011:
-                    if constexpr (METHOD != K_TNCG) { if (lp == 32) return launch_lane<METHOD, 25, 1, 0, 0, 1, true, false, 32>(stream, a, grid_mult); }
+                    if constexpr (METHOD != K_TNCG) {
+                        if (lp == 32) return launch_lane<METHOD, 25, 1, 0, 0, 1, true, false, 32>(stream, a, grid_mult);
+                        if (lp == 48) return launch_lane<METHOD, 25, 1, 0, 0, 1, true, false, 48>(stream, a, grid_mult);
+                    }
                     break;
             }
         } else if (s_load == 50) {
@@ -860,6 +863,7 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
                     case 20081: return launch_lane<METHOD, 13, 2, 0, 0, 8, true>(stream, a, grid_mult);
                     case 30081: return launch_lane<METHOD, 13, 3, 0, 0, 8, true>(stream, a, grid_mult);
                     case 40041: return launch_lane<METHOD, 13, 4, 0, 0, 4, true>(stream, a, grid_mult);
+                    case 140041: if (lp == 16) return launch_lane<METHOD, 13, 4, 0, 0, 4, true, false, 16>(stream, a, grid_mult); break;
                 }
             } else {
                 switch (key) {

@@ -187,6 +187,11 @@ int poismf_hip_device_coo_to_cs(const unsigned* d_major, const unsigned* d_minor
 namespace {
 
 constexpr size_t LDS_RESIDENT_LIMIT = 64 * 1024;  // largest tile a single wave may claim
+constexpr int TEAM_LAUNCH_MAX = 32;   // team launches per half-sweep call (one per team size: <= 22 lane-team sizes + the giant rows + the register teams' shapes)
+// layout of poismf_hip_session::d_team_err, in words: [0] team launches that gave up and were re-run since the word was last read, [1] spare,
+// [2 + i] set by team launch i of the current half when it gives up, [2 + TEAM_LAUNCH_MAX + i] rows launch i found unchanged (TNCG early stop:
+// added to the half's counter only when the launch's results are kept)
+constexpr int TEAM_ERR_WORDS = 2 + 2 * TEAM_LAUNCH_MAX;
 constexpr int MAX_LAUNCHES = 256;  // launches per half-sweep call that get a row-queue head: length classes are multiples of 16 up to 256, of 64
                                    // up to 2048, then powers of two (<= 60 per segment); a call over several segments concatenates their bins
 
@@ -241,19 +246,19 @@ struct poismf_hip_session {
     unsigned* d_counter = nullptr;
     unsigned* d_queue = nullptr;      // one row-queue head per launch of a half-sweep
     unsigned long long* d_team = nullptr;   // team launches (plan.hpp, TEAM_*): allocated by the first one
-    unsigned long long* d_giant = nullptr;  // giant-row team launches (row_eval.hpp, GT_*): allocated by the first one
-    unsigned long long* d_lane_team = nullptr;   // lane-team launches (same layout; they follow one another on the main stream, beside the giant rows' launch)
+    unsigned long long* d_gt = nullptr;     // giant-row and lane-team launches (row_eval.hpp, GT_*): one GT_BUF_BYTES area PER LAUNCH of a half, zeroed together before the first
+    size_t gt_areas = 0, team_areas = 0;    // areas d_gt / d_team hold
     unsigned* d_arrive = nullptr;           // workgroups of the forked long-row launch that have started (half_sweep_impl)
     unsigned long long gate_budget = 200000;   // ticks of the wall clock the hold-back gate waits at most: 2 ms (session_alloc)
-    unsigned* d_team_err = nullptr;         // [0] set by a team launch that gave up, [1] team launches re-run on the streamed path so far; [2], [3]: the same for the
-                                            // giant-row launch, which runs on the second stream BESIDE the main stream's team launches (its own error word, its own buffer)
-    real_t* d_team_backup = nullptr;        // the rows a team launch starts from (restored before its re-run)
-    real_t* d_giant_backup = nullptr;       // the same for the giant-row launch (second stream: its own copy)
-    size_t giant_backup_elems = 0;
-    size_t team_backup_elems = 0;
+    unsigned* d_team_err = nullptr;         // TEAM_ERR_WORDS words (above): give-ups so far, and an error word and a tally per team launch of the current half
+    real_t* d_team_backup = nullptr;        // the rows the team launches of a half start from, launch after launch (restored before a re-run)
+    unsigned* d_team_eval_backup = nullptr; // profiling sessions: those rows' evaluation counters (a re-run must not count an abandoned launch's evaluations)
+    size_t team_backup_elems = 0, team_eval_backup_rows = 0;
     bool team_launched = false;             // since the words were last read
     int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
     bool partials_given = false;      // d_partial already holds every block's partial sum for the NEXT half-sweep (poismf_hip_session_partials_ready)
+    const real_t* partials_of = nullptr;   // ... of THIS factor (the last poismf_hip_session_colsum_partial's): a half-sweep over the other factor, a factor
+                                      // written since, or a half with a caller-supplied sum does not take them for its own
     bool profiling = false;
     std::vector<ProfRec> prof;
     std::vector<LaunchRec> lprof;
@@ -281,18 +286,24 @@ __global__ __launch_bounds__(256) void rebase_indptr_kernel(unsigned long long* 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) indptr[i] -= base;
 }
 // ---- a team launch that gives up must not cost the fit (reg_eval.hpp, M_ > 1: an exchange between CUs timed out) -----------
-// The rows a team launch covers are saved first; if the launch sets the error word, they are put back and the same rows run
-// on the streamed LDS kernel (gated on that word, so the healthy case pays three empty launches and one copy of the rows).
-__global__ __launch_bounds__(256) void team_save_rows_kernel(const real_t* M, const RowDesc* desc, unsigned nrows, unsigned row_offset, int k, real_t* backup)
+// The rows the team launches of a half cover are saved BEFORE the half's first launch (empty chip); AFTER its last launch has ended, every team
+// launch whose error word is set has its rows put back and run again on the streamed LDS kernel (both gated on that word), and one fold kernel
+// settles the counters.  Rounds 2-5 bracketed every team launch with these kernels on the launch's own stream: each of them then queued for a
+// wave slot behind the other stream's persistent 512-register workgroups (round 5's profile: a restore kernel whose body is one compare, 13 ms
+// on average, 8 per C5 sweep) and held the next team launch back.  Now a team launch is ONE dispatch and the healthy case pays its
+// bookkeeping where nothing else is resident.
+__global__ __launch_bounds__(256) void team_save_rows_kernel(const real_t* M, const RowDesc* desc, unsigned nrows, unsigned row_offset, int k, real_t* backup,
+                                                             const unsigned* eval_rows, unsigned* eval_backup)
 {
     const size_t n = (size_t)nrows * (size_t)k;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / (size_t)k, c = i % (size_t)k;
         backup[i] = M[(size_t)(row_offset + desc[r].lrow) * (size_t)k + c];
+        if (eval_rows != nullptr && c == 0) eval_backup[r] = eval_rows[desc[r].lrow];
     }
 }
 __global__ __launch_bounds__(256) void team_restore_rows_kernel(real_t* M, real_t* Mp, int ldM, const RowDesc* desc, unsigned nrows, unsigned row_offset,
-                                                                int k, const real_t* backup, const unsigned* err)
+                                                                int k, const real_t* backup, const unsigned* err, unsigned* eval_rows, const unsigned* eval_backup)
 {
     if (*err == 0) return;
     const size_t n = (size_t)nrows * (size_t)k;
@@ -301,11 +312,19 @@ __global__ __launch_bounds__(256) void team_restore_rows_kernel(real_t* M, real_
         const size_t row = (size_t)(row_offset + desc[r].lrow);
         M[row * (size_t)k + c] = backup[i];
         if (Mp != nullptr) Mp[row * (size_t)ldM + c] = backup[i];
+        if (eval_rows != nullptr && c == 0) eval_rows[desc[r].lrow] = eval_backup[r];
     }
 }
-__global__ void team_fold_err_kernel(unsigned* err)
+// After the re-runs: a launch that gave up is counted ([0]) and its own tally of unchanged rows dropped (its re-run counted them again, straight
+// into the half's counter, ref: src/poismf.c:393-403); a launch that kept its results adds its tally.  The per-launch words are left zeroed.
+__global__ void team_fold_kernel(unsigned* err, int n, unsigned* n_unchanged)
 {
-    if (err[0] != 0) { err[1] += 1; err[0] = 0; }
+    for (int i = 0; i < n; i++) {
+        if (err[2 + i] != 0) err[0] += 1;
+        else if (n_unchanged != nullptr) *n_unchanged += err[2 + TEAM_LAUNCH_MAX + i];
+        err[2 + i] = 0;
+        err[2 + TEAM_LAUNCH_MAX + i] = 0;
+    }
 }
 
 // The hold-back of a half-sweep's other bins behind its forked long-row launch (poismf_hip_half_sweep): one wave that returns when `goal`
@@ -558,6 +577,8 @@ template <int NC> int launch_colsum_partial(poismf_hip_session* s, const real_t*
 {
     const int nw = colsum_blocks_for(s, n);
     if (b_lo < 0 || b_hi > nw || b_lo > b_hi) return 1;
+    s->partials_of = M;
+    s->partials_given = false;
     if (b_hi > b_lo)
         hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(b_hi - b_lo), dim3(WAVE * COLSUM_BLOCK_WAVES), 0, s->stream, M, n, (int)s->k,
                            s->d_partial, (unsigned)b_lo, (unsigned)nw);
@@ -569,7 +590,8 @@ template <int NC> int launch_colsum(poismf_hip_session* s, const real_t* M, size
     const int nw = colsum_blocks_for(s, n);
     // first stage: all blocks here, or only [b_lo, b_hi) (the others are the peers' and have been put into d_partial by the caller), or none
     int b_lo = 0, b_hi = nw;
-    if (s->partials_given) { b_lo = b_hi = 0; s->partials_given = false; }
+    if (s->partials_given && s->partials_of == M) { b_lo = b_hi = 0; }
+    s->partials_given = false;        // (one shot, whoever consumes or declines it)
     if (b_hi > b_lo)
         hipLaunchKernelGGL((colsum_partial_kernel<real_t, NC>), dim3(b_hi - b_lo), dim3(WAVE * COLSUM_BLOCK_WAVES), 0, s->stream, M, n, (int)s->k,
                            s->d_partial, (unsigned)b_lo, (unsigned)nw);
@@ -687,10 +709,10 @@ static poismf_hip_session* session_alloc(int device, void* stream, size_t dimA, 
     if (pmf_alloc(&s->d_bsum, k * sizeof(real_t) + slack, s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_partial, (size_t)s->colsum_waves * k * sizeof(real_t), s->stream) != hipSuccess) return fail();
     if (pmf_alloc(&s->d_counter, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 24), s->stream) != hipSuccess) return fail();   // (+8: team launches of a half with too many bins for the shared heads; +8: their streamed re-runs)
+    if (pmf_alloc(&s->d_queue, sizeof(unsigned) * (MAX_LAUNCHES + 2 * TEAM_LAUNCH_MAX), s->stream) != hipSuccess) return fail();   // (+: a head of its own for every team launch of a half, and one for its streamed re-run)
     if (pmf_alloc(&s->d_arrive, sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (pmf_alloc(&s->d_team_err, 4 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
-    if (hipMemsetAsync(s->d_team_err, 0, 4 * sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (pmf_alloc(&s->d_team_err, TEAM_ERR_WORDS * sizeof(unsigned), s->stream) != hipSuccess) return fail();
+    if (hipMemsetAsync(s->d_team_err, 0, TEAM_ERR_WORDS * sizeof(unsigned), s->stream) != hipSuccess) return fail();
     if (cached_stream(device, &s->aux_stream)) return fail();
     if (hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess) return fail();
     if (hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming) != hipSuccess) return fail();
@@ -810,13 +832,12 @@ void poismf_hip_session_destroy(poismf_hip_session* s)
     pmf_free(s->d_partial, s->stream);
     pmf_free(s->d_counter, s->stream);
     pmf_free(s->d_queue, s->stream);
-    pmf_free(s->d_giant, s->stream);
-    pmf_free(s->d_lane_team, s->stream);
+    pmf_free(s->d_gt, s->stream);
     pmf_free(s->d_team, s->stream);
     pmf_free(s->d_team_err, s->stream);
     pmf_free(s->d_arrive, s->stream);
     pmf_free(s->d_team_backup, s->stream);
-    pmf_free(s->d_giant_backup, s->stream);
+    pmf_free(s->d_team_eval_backup, s->stream);
     (void)hipStreamSynchronize(s->stream);   // the stream-ordered frees have run
     if (aux) release_stream(s->device, aux);
     if (own) release_stream(s->device, own);
@@ -832,7 +853,11 @@ size_t poismf_hip_set_device_cache_mb(size_t mb) { return pmf_set_cache_limit_mb
 real_t* poismf_hip_session_A(poismf_hip_session* s) { s->padded_fresh[1] = false; return s->dA; }
 real_t* poismf_hip_session_B(poismf_hip_session* s) { s->padded_fresh[0] = false; return s->dB; }
 // ... and whoever keeps such a pointer says so after every later write (which = 0: B was written, 1: A)
-void poismf_hip_session_factors_dirty(poismf_hip_session* s, int which) { s->padded_fresh[which ? 1 : 0] = false; }
+void poismf_hip_session_factors_dirty(poismf_hip_session* s, int which)
+{
+    s->padded_fresh[which ? 1 : 0] = false;
+    if (s->partials_of == (which ? s->dA : s->dB)) { s->partials_given = false; s->partials_of = nullptr; }   // partial sums of a factor written since
+}
 
 // ---- the first stage of the column sums, shared between the ranks of a multi-GPU run (ref: src/poismf.c:77-83) -----------------
 // The sum over the fixed factor of half `which` (A for the B half, B for the A half) is cut into poismf_hip_session_colsum_blocks() blocks
@@ -846,7 +871,7 @@ int poismf_hip_session_colsum_partial(poismf_hip_session* s, int which, int b_lo
     return colsum_partial(s, which ? s->dB : s->dA, which ? s->dimB : s->dimA, b_lo, b_hi);
 }
 real_t* poismf_hip_session_partials(poismf_hip_session* s) { return s->d_partial; }
-void poismf_hip_session_partials_ready(poismf_hip_session* s) { s->partials_given = true; }
+void poismf_hip_session_partials_ready(poismf_hip_session* s) { s->partials_given = s->partials_of != nullptr; }
 void* poismf_hip_session_stream(poismf_hip_session* s) { return (void*)s->stream; }
 size_t poismf_hip_session_nnz(poismf_hip_session* s, int which) { return s->half[which ? 1 : 0].nnz; }
 
@@ -883,6 +908,7 @@ int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, 
     HIP_TRY(pmf_upload_big(s->dA, A_host, s->dimA * s->k * sizeof(real_t), s->device, s->stream));
     HIP_TRY(pmf_upload_big(s->dB, B_host, s->dimB * s->k * sizeof(real_t), s->device, s->stream));
     s->padded_fresh[0] = s->padded_fresh[1] = false;
+    s->partials_given = false; s->partials_of = nullptr;
     return 0;
 }
 
@@ -891,13 +917,13 @@ int poismf_hip_session_set_factors(poismf_hip_session* s, const real_t* A_host, 
 static int team_check(poismf_hip_session* s)
 {
     if (!s->team_launched) return 0;
-    unsigned w[4] = { 0, 0, 0, 0 };
-    HIP_TRY(pmf_download(w, s->d_team_err, 4 * sizeof(unsigned), s->stream));
+    unsigned w[2] = { 0, 0 };
+    HIP_TRY(pmf_download(w, s->d_team_err, 2 * sizeof(unsigned), s->stream));
     s->team_launched = false;
-    if (w[1] + w[3] != 0) {
+    if (w[0] != 0) {
         fprintf(stderr, "poismf_hip: %u multi-CU row launch(es) timed out waiting for a partner CU and were re-run on the streamed path "
-                        "(results are valid; another process or kernel is holding CUs)\n", w[1] + w[3]);
-        HIP_TRY(hipMemsetAsync(s->d_team_err, 0, 4 * sizeof(unsigned), s->stream));
+                        "(results are valid; another process or kernel is holding CUs)\n", w[0]);
+        HIP_TRY(hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream));
     }
     return 0;
 }
@@ -1021,6 +1047,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     //   A half: * (-step) twice      ref: src/poismf.c:573-577 (quirk Q1)
     real_t neg_step = -step_size;
     if (bsum_override != nullptr) {
+        s->partials_given = false;   // (declared for a half that computes its own sum: not for a later one)
         neg_step = neg_step_override;
         HIP_TRY(pmf_upload(s->d_bsum, bsum_override, s->k * sizeof(real_t), s->stream));
     } else if (prologue) {
@@ -1090,6 +1117,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // solver) are merged into one launch.
     struct Launch { unsigned begin, count; TileGeom geom; int nw; int reg_S; int team; unsigned long long nnz; int lane_L = 0, lane_A = 0, lane_LL = 0, lane_small = 0, lane_LP = 0, lane_tx = 0; };
     std::vector<Launch> launches;
+    // (every team launch of a call gets a row-queue head, an error word and a buffer area of its own: no more than TEAM_LAUNCH_MAX of them; a bin
+    // that would open one more takes the path it has without teams)
+    auto n_team_launches = [&]() { int n = 0; for (const Launch& L : launches) n += L.team > 1; return n; };
     static const bool no_reg = getenv("POISMF_HIP_NO_REGTILE") != nullptr;  // testing knob: LDS engine for every row
     // register engine: factor rows of at most 16 slots (32 for doubles, two slots per lane), and 24-bit row ids / 32-bit
     // byte offsets into the factor
@@ -1134,7 +1164,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             int lane_team = 0;
             static const bool no_lane_teams = getenv("POISMF_HIP_NO_LANE_TEAMS") != nullptr;
             if (ls.waves == 0 && sizeof(real_t) == 8 && g.s_load == 50 && pm == POISMF_TNCG && !no_lane_teams && !no_team && !static_rows_ && b.cls > 384 &&
-                b.cls <= LONG_ROW_NNZ && launches.size() < (size_t)MAX_LAUNCHES - 2) {
+                b.cls <= LONG_ROW_NNZ && n_team_launches() < TEAM_LAUNCH_MAX - 1) {
                 const int m = (int)((b.cls + 383u) / 384u);
                 if (m >= 2 && s->num_cu >= 2 * m) { ls = LaneShape{ 1, 0, 0, 4, 0, 32 }; lane_team = m; }
             }
@@ -1178,7 +1208,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         }
         if (team_ok) {
             // rows whose tile fits the registers of two to four CUs, not of one: a team per row (reg_eval.hpp, M_ > 1)
-            const TeamShape ts = team_shape_for(b.cls);   // by the class bound, never by the longest row that happens to be in the bin: a row's
+            const TeamShape ts = n_team_launches() < TEAM_LAUNCH_MAX - 1 ? team_shape_for(b.cls) : TeamShape{};   // by the class bound, never by the longest row that happens to be in the bin: a row's
             // share of the tile (my_share: C = ceil(nnz / (NW M))) -- and with it its summation order -- must not depend on its shard
             if (ts.members > 0) {
                 if (!launches.empty() && launches.back().team == ts.members && launches.back().reg_S == ts.steps &&
@@ -1211,7 +1241,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             // one workgroup per row, rounds 1-4).  Decided by the solver alone: a row's arithmetic must not depend on its shard.
             static const bool no_giant = getenv("POISMF_HIP_NO_GIANT_TEAMS") != nullptr;
             static const unsigned giant_thr = getenv("POISMF_HIP_GIANT_NNZ") ? (unsigned)std::max(64, atoi(getenv("POISMF_HIP_GIANT_NNZ"))) : LONG_ROW_NNZ;   // testing knob
-            const int giant = (!no_giant && !no_team && !static_rows_ && pm == POISMF_TNCG && b.cls > giant_thr && launches.size() < (size_t)MAX_LAUNCHES - 2 &&
+            const int giant = (!no_giant && !no_team && !static_rows_ && pm == POISMF_TNCG && b.cls > giant_thr && n_team_launches() < TEAM_LAUNCH_MAX - 1 &&
                                s->num_cu >= 2 * GT_M) ? GT_M : 0;
             if (!launches.empty() && launches.back().lane_L == 0 && launches.back().reg_S == 0 && launches.back().nw == LONG_NW && launches.back().team == giant &&
                 launches.back().begin + launches.back().count == b.begin)
@@ -1262,6 +1292,64 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const bool no_arrive = getenv("POISMF_HIP_NO_ARRIVE_WAIT") != nullptr;   // testing knob
     const bool hold_back = forked && any_long && !no_arrive && !teams_on_main;
     if (hold_back) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, sizeof(unsigned), s->stream));
+    // ---- everything the team launches of this call need, once, on the main stream, before anything of the half is on the chip: a zeroed
+    // buffer area, row-queue head (+ one for the re-run), error word and tally per launch, and a copy of the rows they start from
+    struct TeamSlot { size_t backup_at, eval_at; int area; };   // per team launch, in launch order
+    std::vector<TeamSlot> tslots;
+    {
+        size_t elems = 0, rows = 0;
+        int n_gt = 0, n_reg = 0;
+        for (const Launch& L : launches) {
+            if (L.team <= 1) continue;
+            const bool gt = L.lane_L > 0 || (L.team == GT_M && L.reg_S == 0);   // lane teams and giant rows share the GT_* layout
+            tslots.push_back({ elems, rows, gt ? n_gt++ : n_reg++ });
+            elems += (size_t)L.count * s->k;
+            rows += L.count;
+        }
+        if (!tslots.empty()) {
+            // (growing a buffer frees it first, i.e. synchronises the device: sized for the whole half at once, and only ever grown)
+            if ((size_t)n_gt > s->gt_areas) {
+                pmf_free(s->d_gt, s->stream); s->d_gt = nullptr; s->gt_areas = 0;
+                HIP_TRY(pmf_alloc(&s->d_gt, (size_t)n_gt * (size_t)GT_BUF_BYTES, s->stream));
+                s->gt_areas = (size_t)n_gt;
+            }
+            if ((size_t)n_reg > s->team_areas) {
+                pmf_free(s->d_team, s->stream); s->d_team = nullptr; s->team_areas = 0;
+                HIP_TRY(pmf_alloc(&s->d_team, (size_t)n_reg * (size_t)TEAM_BUF_BYTES, s->stream));
+                s->team_areas = (size_t)n_reg;
+            }
+            if (elems > s->team_backup_elems) {
+                pmf_free(s->d_team_backup, s->stream); s->d_team_backup = nullptr; s->team_backup_elems = 0;
+                HIP_TRY(pmf_alloc(&s->d_team_backup, elems * sizeof(real_t), s->stream));
+                s->team_backup_elems = elems;
+            }
+            if (a.eval_rows != nullptr && rows > s->team_eval_backup_rows) {
+                pmf_free(s->d_team_eval_backup, s->stream); s->d_team_eval_backup = nullptr; s->team_eval_backup_rows = 0;
+                HIP_TRY(pmf_alloc(&s->d_team_eval_backup, rows * sizeof(unsigned), s->stream));
+                s->team_eval_backup_rows = rows;
+            }
+            // (a giant / lane team's area is used up to its teams' words: the whole areas are zeroed all the same -- n x 4.6 MB, microseconds on an
+            // empty chip, where round 5 zeroed one area per launch between persistent kernels)
+            if (n_gt) HIP_TRY(hipMemsetAsync(s->d_gt, 0, (size_t)n_gt * (size_t)GT_BUF_BYTES, s->stream));
+            if (n_reg) HIP_TRY(hipMemsetAsync(s->d_team, 0, (size_t)n_reg * (size_t)TEAM_BUF_BYTES, s->stream));
+            HIP_TRY(hipMemsetAsync(s->d_queue + MAX_LAUNCHES, 0, sizeof(unsigned) * 2 * TEAM_LAUNCH_MAX, s->stream));
+            HIP_TRY(hipMemsetAsync(s->d_team_err + 2, 0, sizeof(unsigned) * 2 * TEAM_LAUNCH_MAX, s->stream));
+            size_t ti = 0;
+            for (const Launch& L : launches) {
+                if (L.team <= 1) continue;
+                const size_t need = (size_t)L.count * s->k;
+                hipLaunchKernelGGL(team_save_rows_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, (size_t)s->num_cu * 8)), dim3(256), 0, s->stream,
+                                   M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, s->d_team_backup + tslots[ti].backup_at,
+                                   (const unsigned*)a.eval_rows, a.eval_rows != nullptr ? s->d_team_eval_backup + tslots[ti].eval_at : nullptr);
+                ti++;
+            }
+            HIP_TRY(hipGetLastError());
+            s->team_launched = true;
+        }
+    }
+    struct TeamRerun { HalfArgs<real_t> af; OneLaunch of; unsigned begin, count; size_t slot; };
+    std::vector<TeamRerun> reruns;   // what each team launch becomes if it gives up (issued, gated, after the join)
+    size_t team_no = 0;
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_fork, s->stream));
         HIP_TRY(hipStreamWaitEvent(s->aux_stream, s->ev_fork, 0));
@@ -1276,7 +1364,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             const char* m = is_pg ? "pg" : p->method == POISMF_EVAL ? "eval" : pm == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
             if (L.lane_L > 0 && L.team > 1) snprintf(txt, sizeof txt, "half_sweep_lane_team_kernel<%s,%s,KS=%d,V=%d,L=0+%d,NW=%d,M=%d> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_LP, L.nw, L.team, L.count);
-            else if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP == 32 ? "+32" : L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.lane_tx == 48 ? ",TX=48" : L.lane_tx == 64 ? ",TX=64" : "", L.count);
+            else if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP == 48 ? "+48" : L.lane_LP == 32 ? "+32" : L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.lane_tx == 48 ? ",TX=48" : L.lane_tx == 64 ? ",TX=64" : "", L.count);
             else if (L.team == GT_M && L.reg_S == 0) snprintf(txt, sizeof txt, "half_sweep_giant_kernel<%s,%s,NW=%d,M=%d,streamed cap=%d> rows=%u;", t, m, L.nw, L.team, L.geom.cap, L.count);
             else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
             else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
@@ -1303,47 +1391,24 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         // the queue (CG fp32 on C2: 3.87 ms with tickets, 3.35 ms without).
         const bool one_wave_reg = (L.reg_S > 0 || L.lane_L > 0) && L.nw == 1;
         if (one_wave_reg) a.queue = nullptr;
-        a.team_buf = nullptr; a.team_err = s->d_team_err;
-        unsigned* terr = s->d_team_err;
+        a.team_buf = nullptr; a.team_err = s->d_team_err + 2;
+        a.n_unchanged = s->d_counter;
+        unsigned* terr = s->d_team_err + 2;
         const bool giant = L.team == GT_M && L.reg_S == 0 && L.lane_L == 0;
         const bool lane_team = L.team > 1 && L.lane_L > 0;
         a.team_members = (unsigned)std::max(1, L.team);
-        // (a giant-row team launch and everything that brackets it -- the copy of its rows, their restoration and re-run -- lives on the stream
-        // the long rows run on)
+        // (a giant-row team launch lives on the stream the long rows run on)
         hipStream_t tst = (giant || (lane_team && !teams_on_main)) ? long_stream : s->stream;
+        const size_t my_slot = team_no;
         if (L.team > 1) {
-            if (a.queue == nullptr) {            // teams always draw their rows from a queue
-                a.queue = s->d_queue + MAX_LAUNCHES + (launch_no % 8);
-                HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(unsigned), s->stream));
-            }
-            if (giant || lane_team) {
-                unsigned long long*& buf = giant ? s->d_giant : s->d_lane_team;
-                if (buf == nullptr && pmf_alloc(&buf, (size_t)GT_BUF_BYTES, s->stream) != hipSuccess) return 1;
-                HIP_TRY(hipMemsetAsync(buf, 0, (size_t)GT_BUF_BYTES, tst));
-                a.team_buf = buf;
-                if (giant) { terr = s->d_team_err + 2; a.team_err = terr; }
-            } else {
-                if (s->d_team == nullptr && pmf_alloc(&s->d_team, (size_t)TEAM_BUF_BYTES, s->stream) != hipSuccess) return 1;
-                HIP_TRY(hipMemsetAsync(s->d_team, 0, (size_t)TEAM_BUF_BYTES, s->stream));
-                a.team_buf = s->d_team;
-            }
-            s->team_launched = true;
-            // the rows this launch starts from, in case it gives up
-            const size_t need = (size_t)L.count * s->k;
-            real_t*& backup = giant ? s->d_giant_backup : s->d_team_backup;
-            size_t& backup_elems = giant ? s->giant_backup_elems : s->team_backup_elems;
-            if (need > backup_elems) {
-                // (sized for the largest team launch of this half at once: growing it launch by launch would free -- i.e. synchronise the device -- each time)
-                size_t want = need;
-                for (const Launch& L2 : launches)
-                    if (L2.team > 1 && (L2.team == GT_M && L2.reg_S == 0 && L2.lane_L == 0) == giant) want = std::max(want, (size_t)L2.count * s->k);
-                pmf_free(backup, s->stream);
-                backup = nullptr; backup_elems = 0;
-                HIP_TRY(pmf_alloc(&backup, want * sizeof(real_t), s->stream));
-                backup_elems = want;
-            }
-            hipLaunchKernelGGL(team_save_rows_kernel, dim3((unsigned)std::min<size_t>((need + 255) / 256, (size_t)s->num_cu * 8)), dim3(256), 0, tst,
-                               M, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k, backup);
+            // one dispatch: its queue head, buffer area, error word and tally are its own and were zeroed before the half began
+            team_no++;
+            a.queue = s->d_queue + MAX_LAUNCHES + my_slot;            // teams always draw their rows from a queue
+            terr = s->d_team_err + 2 + my_slot;
+            a.team_err = terr;
+            a.n_unchanged = s->d_team_err + 2 + TEAM_LAUNCH_MAX + my_slot;   // kept only if the launch's results are (team_fold_kernel)
+            a.team_buf = (giant || lane_team) ? s->d_gt + (size_t)tslots[my_slot].area * (size_t)(GT_BUF_BYTES / 8)
+                                              : s->d_team + (size_t)tslots[my_slot].area * (size_t)(TEAM_BUF_BYTES / 8);
         }
         a.gate = nullptr;
         const bool is_long = L.nw > 1 && L.reg_S == 0 && L.lane_L == 0;
@@ -1400,17 +1465,14 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 hipLaunchKernelGGL(hold_back_gate_kernel, dim3(1), dim3(1), 0, s->stream, s->d_arrive, arrive_goal, s->gate_budget);
             }
             if (!rc && L.team > 1) {
-                // if the team launch gave up: rows back to where they started, the same rows on the streamed LDS kernel, note it
-                hipLaunchKernelGGL(team_restore_rows_kernel, dim3((unsigned)std::min<size_t>(((size_t)L.count * s->k + 255) / 256, (size_t)s->num_cu * 8)),
-                                   dim3(256), 0, tst, M, Mp, (int)s->ld, h.d_desc + L.begin, L.count, (unsigned)h.row_begin, (int)s->k,
-                                   giant ? s->d_giant_backup : s->d_team_backup, terr);
+                // if the team launch gives up: rows back to where they started, the same rows on the streamed LDS kernel -- after the join (below)
                 HalfArgs<real_t> af = a;
                 // (a.geom is the LDS engine's geometry for the launch's longest length class: what these rows take without teams)
                 af.team_buf = nullptr;
                 af.gate = terr;
                 af.arrive = nullptr;
-                af.queue = s->d_queue + MAX_LAUNCHES + 8 + (launch_no % 8);
-                HIP_TRY(hipMemsetAsync(af.queue, 0, sizeof(unsigned), tst));
+                af.n_unchanged = s->d_counter;
+                af.queue = s->d_queue + MAX_LAUNCHES + TEAM_LAUNCH_MAX + my_slot;
                 if (lane_team) {   // (a lane launch carries the one-wave LDS geometry of its class: the eight-wave streamed kernel wants its own)
                     af.geom.resident = 0;
                     af.geom.prefetch = prefetch_enabled() ? 1 : 0;
@@ -1423,16 +1485,11 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
                 OneLaunch of = o;
                 of.reg_S = 0; of.nw = (giant || lane_team) ? LONG_NW : 1; of.team = 0; of.lane_L = 0; of.lane_A = 0; of.lane_LL = 0; of.lane_small = 0; of.lane_LP = 0; of.lane_tx = 0;
                 of.s_load = af.geom.s_load;
-                of.bin_stream = tst; of.long_stream = tst;
+                of.main_stream = s->stream; of.bin_stream = s->stream; of.long_stream = s->stream;
                 of.lds = lds_bytes_per_block(af.geom, sizeof(real_t), of.nw);
                 of.grid = (giant || lane_team) ? (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu)
                                 : (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * std::max<size_t>(1, std::min<size_t>(16, LDS_PER_CU / of.lds)) * 2);
-#ifdef PMF_LANE_ONLY   // (development builds without the streamed kernels: no re-run)
-                rc = 0;
-#else
-                rc = launch_one(p->method, of, af);
-#endif
-                hipLaunchKernelGGL(team_fold_err_kernel, dim3(1), dim3(1), 0, tst, terr);
+                reruns.push_back({ af, of, L.begin, L.count, my_slot });
             }
             if (s->profiling) {
                 HIP_TRY(hipEventRecord(lr.t1, lst));
@@ -1444,6 +1501,21 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     if (forked) {
         HIP_TRY(hipEventRecord(s->ev_join, s->aux_stream));
         HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    }
+    // the team launches' epilogue, on a chip that has nothing else resident: per launch a restore and a streamed re-run that return at once unless
+    // the launch's error word is set, then the fold
+    for (const TeamRerun& r : reruns) {
+        hipLaunchKernelGGL(team_restore_rows_kernel, dim3((unsigned)std::min<size_t>(((size_t)r.count * s->k + 255) / 256, (size_t)s->num_cu * 8)),
+                           dim3(256), 0, s->stream, M, Mp, (int)s->ld, h.d_desc + r.begin, r.count, (unsigned)h.row_begin, (int)s->k,
+                           s->d_team_backup + tslots[r.slot].backup_at, s->d_team_err + 2 + r.slot, a.eval_rows,
+                           a.eval_rows != nullptr ? s->d_team_eval_backup + tslots[r.slot].eval_at : nullptr);
+#ifndef PMF_LANE_ONLY   // (development builds without the streamed kernels: no re-run)
+        if (launch_one(p->method, r.of, r.af)) return 1;
+#endif
+    }
+    if (!reruns.empty()) {
+        hipLaunchKernelGGL(team_fold_kernel, dim3(1), dim3(1), 0, s->stream, s->d_team_err, (int)tslots.size(), a.early_stop ? s->d_counter : nullptr);
+        HIP_TRY(hipGetLastError());
     }
     if (s->profiling) {
         HIP_TRY(hipEventRecord(rec.t1, s->stream));
@@ -1696,8 +1768,10 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
 // thread per device.  After a half every device holds the rows it updated; they travel DIRECTLY to every peer, device to
 // device (hipMemcpyPeerAsync on the owner's stream: over xGMI's full mesh all seven links of a GPU carry one shard each at the
 // same time; no staging, no collective to wait for the slowest rank), and the next half starts when all of them have landed.
-// The k-vector column sums are recomputed by every device from its replica (deterministic, identical bits everywhere), which
-// is what replaces the north-star's all-reduce; TNCG's early-stop counter is summed on the host.
+// The k-vector column sums: every device needs the same bits, so the sum is cut into fixed blocks whose partial sums depend on the
+// block number alone; device d computes its 1 / D of the blocks over its replica, the [blocks x k] partials travel like the rows, and
+// every device runs the fixed-order second stage (round 5; rounds 2-4 had every device recompute the whole sum) -- which is what
+// replaces the north-star's all-reduce with sharding-independent bits; TNCG's early-stop counter is summed on the host.
 // A device may be listed more than once (POISMF_HIP_DEVICES=0,0): the shards then share that GPU, which is how the one-GPU
 // test exercises every line of this path (tests/test_gpu_multi.py); results equal the single-session run bit for bit, since a
 // row's arithmetic depends on its length class alone and the column sums are computed in one fixed order.

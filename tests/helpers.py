@@ -118,3 +118,51 @@ def check_topn(a_vec, B, idx, scores, include_ix, exclude_ix, n_top, rtol):
     left_out = np.setdiff1d(cand, idx)
     if len(left_out):
         assert true[left_out].max() <= s[-1] + tol
+
+
+def _reorder_rows(cs, mode, rng):
+    """the same CSR / CSC matrix with the nonzeros of every row stored in another order (reversed / shuffled)"""
+    data, idx, ptr = cs[0].copy(), cs[1].copy(), cs[2]
+    p = ptr.astype(np.int64)
+    for r in range(len(p) - 1):
+        a, b = p[r], p[r + 1]
+        if b - a > 1:
+            o = np.arange(b - a)[::-1] if mode == "rev" else rng.permutation(b - a)
+            data[a:b] = data[a:b][o]
+            idx[a:b] = idx[a:b][o]
+    return data, idx, ptr
+
+
+def tncg_yardstick(use_float, csr, csc, A0, B0, args, nthreads=8):
+    """(A, B of the checker, objective of the checker, self-variance): how far the REFERENCE's arithmetic moves on this very problem when only
+    the order of its sums changes.  TNC stops a row when its objective moves by less than ftol = 1e-4 of itself (ref: src/poismf.c:383-391,
+    src/tnc.c:909-915) and takes its Hessian products from finite differences of step ~1.5e-8, so rounding-level differences decide where a
+    row ends; how much of that reaches the TOTAL is a property of the problem (how much of it a few long rows carry).  Six runs on the CPU:
+    the two summation flavours of the k-length sums -- the BLAS-routed restatement that reproduces the compiled reference bit for bit
+    (`checker`, the first run: what GPU results are judged against) and the plain left-to-right loops -- each on the matrix as given, with
+    every row's nonzeros stored in reverse order, and shuffled (the same matrix: the ABI does not ask for sorted rows; this is
+    the kind of difference a device that adds a row's nonzeros in tree order has).  self-variance = the largest relative distance of the
+    five others' objectives from the checker's.  SURVEY 8c's end-to-end bound for TNCG fp64 is 1e-5: `tncg_bound` lets a test exceed it
+    only by a multiple of this measured spread, and the tests print both numbers."""
+    from oracle import bindings
+    rng = np.random.default_rng(0)
+    first, objs = None, []
+    for lib in (checker(use_float, "tncg"), bindings.Oracle(use_float)):
+        for mode in (None, "rev", "perm"):
+            c1 = csr if mode is None else _reorder_rows(csr, mode, rng)
+            c2 = csc if mode is None else _reorder_rows(csc, mode, rng)
+            A, B = A0.copy(), B0.copy()
+            rc = lib.run_poismf(A, c1[0], c1[2], c1[1], B, c2[0], c2[2], c2[1], args["l2_reg"], args["l1_reg"], args["w_mult"],
+                                args["step_size"], "tncg", args["limit_step"], args["niter"], args["maxupd"], args["early_stop"],
+                                args["reuse_prev"], True, nthreads)
+            assert rc == 0
+            objs.append(harness.poisson_objective(A, B, csr, args["l2_reg"], args["l1_reg"], args["w_mult"]))
+            if first is None:
+                first = (A, B)
+    return first[0], first[1], objs[0], max(abs(o - objs[0]) for o in objs[1:]) / abs(objs[0])
+
+
+def tncg_bound(self_variance, floor=1e-5):
+    """SURVEY 8c's 1e-5, or twice the largest distance the reference's own arithmetic shows on the same rows under another order of its
+    sums (tncg_yardstick: five alternatives), whichever is larger"""
+    return max(floor, 2.0 * self_variance)

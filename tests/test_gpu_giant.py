@@ -12,7 +12,6 @@ import pytest
 
 from poismf_amd import harness
 from tests import helpers as H
-from tests.test_gpu_parity import compare, oracle_run
 from tests.test_gpu_regtile import ragged_problem
 
 pytestmark = pytest.mark.gpu
@@ -36,6 +35,10 @@ s = api.Session(csr, csc, A0.shape[0], B0.shape[0], k, prec)
 s.set_factors(A0, B0)
 s.half_sweep(1, s.make_params("tncg", 1e3, maxupd=20), 1e-7, 1.0)
 print("PLAN", " ".join(name for name, _ in s.plan(1)))
+# the early-stop statistic of a further half-sweep from the fitted factors (ref: src/poismf.c:393-403): rows that moved by <= 1e-4
+s.set_factors(A, B)
+n1 = s.half_sweep(1, s.make_params("tncg", 1e3, w_mult={w}, maxupd={maxupd}, early_stop=True, reuse_prev=True), 1e-7, 1.0, want_unchanged=True)
+print("UNCHANGED", n1)
 s.close()
 np.save({out!r}, np.stack(outs))
 """
@@ -50,7 +53,12 @@ def run_child(tmp_path, tag, env, k=100, prec=False, repeat=1, maxupd=1500, w=1.
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, k=k, prec=prec, repeat=repeat, maxupd=maxupd, w=w, niter=niter)], check=True,
                        env=e, cwd=ROOT, timeout=900, capture_output=True, text=True)
     plan = [l for l in r.stdout.splitlines() if l.startswith("PLAN")][0]
+    global LAST_UNCHANGED
+    LAST_UNCHANGED = int([l for l in r.stdout.splitlines() if l.startswith("UNCHANGED")][0].split()[1])
     return np.load(out), plan, r.stderr
+
+
+LAST_UNCHANGED = None   # the UNCHANGED count the most recent child printed
 
 
 NO_TEAMS = any(os.environ.get(v) for v in ("POISMF_HIP_NO_TEAM", "POISMF_HIP_NO_GIANT_TEAMS", "POISMF_HIP_STATIC_ROWS", "POISMF_HIP_NO_LONGROW"))
@@ -65,19 +73,19 @@ def test_giant_team_rows_vs_oracle_and_repeatable(tmp_path, k, prec, w):
     csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, k, prec, seed=33)
     l2, _, _ = harness.auto_defaults("tncg", k)
     args = dict(l2_reg=l2, l1_reg=0.0, w_mult=w, step_size=1e-7, limit_step=True, niter=2, maxupd=1500, early_stop=True, reuse_prev=False)
-    Ar, Br = oracle_run(prec, csr, csc, A0, B0, "tncg", args)
+    # TNCG fp64 end to end, objective within 1e-5 -- or within 2 x what the REFERENCE's own arithmetic moves by on THIS problem when
+    # only the order of its sums changes (tests/helpers.py, tncg_yardstick: its two k-sum flavours x the rows' nonzeros as given / reversed /
+    # shuffled; measured in the build container: k = 100 1.8e-4, k = 50 5.7e-5, k = 20 5.2e-8 -- three rows of 2500 .. 9000 nonzeros are most
+    # of the total and each stops within ftol = 1e-4 of itself; round 6 measured the GPU at 5.0e-5 for k = 50).  The sharp check of the
+    # team's sums is test_giant_team_sums_match_the_one_workgroup_path below.
+    Ar, Br, orf, self_var = H.tncg_yardstick(prec, csr, csc, A0, B0, args)
     nA = A0.size
     A, B = res[0][:nA].reshape(A0.shape), res[0][nA:].reshape(B0.shape)
     assert not A[-1].any()
-    # TNC stops a row when its objective moves by less than ftol = 1e-4 of itself (ref: src/poismf.c:383-391, src/tnc.c:909-915): two summation
-    # orders of the same arithmetic end up to ~1e-4 of a ROW's objective apart, and here three rows of 2500 .. 9000 nonzeros are most of the
-    # total (measured: 5e-5 .. 1.7e-4; the suite's 5e-5 is for rows of at most 1500 nonzeros).  The sharp check of the team's sums is
-    # test_giant_team_sums_match_the_one_workgroup_path below.
     assert np.isfinite(A).all() and np.isfinite(B).all() and A.min() >= 0 and B.min() >= 0
     og = harness.poisson_objective(A, B, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
-    orf = harness.poisson_objective(Ar, Br, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
-    print(f"giant teams k={k} w={w}: objective gpu {og:.10g} checker {orf:.10g} rel {abs(og - orf) / abs(orf):.3g}")
-    assert abs(og - orf) <= 5e-4 * abs(orf)
+    print(f"giant teams k={k} w={w}: objective gpu {og:.10g} checker {orf:.10g} rel {abs(og - orf) / abs(orf):.3g} (reference flavours among themselves {self_var:.3g})")
+    assert abs(og - orf) <= H.tncg_bound(self_var) * abs(orf), (abs(og - orf) / abs(orf), self_var)
 
 
 def test_giant_team_fp32_is_finite_and_close_to_the_one_workgroup_path(tmp_path):
@@ -119,7 +127,11 @@ def test_giant_team_and_one_workgroup_paths_agree(tmp_path):
     l2, _, _ = harness.auto_defaults("tncg", 100)
     nA = A0.size
     o = [harness.poisson_objective(r[0][:nA].reshape(A0.shape), r[0][nA:].reshape(B0.shape), csr, l2, 0.0, 1.0) for r in (team, one)]
-    assert abs(o[0] - o[1]) <= 5e-4 * abs(o[1]), o          # (TNC's own stopping tolerance, see above)
+    # two summation orders of the same rows: as far apart as the reference's own runs are on this problem under other summation orders (x 2), no further
+    args = dict(l2_reg=l2, l1_reg=0.0, w_mult=1.0, step_size=1e-7, limit_step=True, niter=2, maxupd=1500, early_stop=True, reuse_prev=False)
+    _, _, _, self_var = H.tncg_yardstick(False, csr, csc, A0, B0, args)
+    print(f"giant teams vs one workgroup per row: objectives {abs(o[0] - o[1]) / abs(o[1]):.3g} apart (reference flavours among themselves {self_var:.3g})")
+    assert abs(o[0] - o[1]) <= H.tncg_bound(self_var) * abs(o[1]), (o, self_var)
 
 
 def test_a_giant_team_that_gives_up_is_rerun_by_one_workgroup_per_row(tmp_path):
@@ -129,16 +141,20 @@ def test_a_giant_team_that_gives_up_is_rerun_by_one_workgroup_per_row(tmp_path):
     if NO_TEAMS:
         pytest.skip("no giant-row team launches under this knob")
     gave, _, err = run_child(tmp_path, "gave_up", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_TEAM_SPIN_LIMIT": "1"})
+    n_gave = LAST_UNCHANGED
     one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_GIANT_NNZ": "256", "POISMF_HIP_NO_GIANT_TEAMS": "1"})
     assert "re-run on the streamed path" in err, err
     assert np.isfinite(gave).all()
     assert np.array_equal(gave, one)
+    # rows an abandoned launch had already finished are solved -- and counted -- again by the re-run: the early-stop statistic must be the
+    # no-team run's, not the sum of both (round 5 counted them twice; the launch's own tally is now dropped when it gives up)
+    assert n_gave == LAST_UNCHANGED and n_gave > 0, (n_gave, LAST_UNCHANGED)
 
 
 # ---- lane teams: k = 100 fp64 TNCG rows of 385 .. 8192 nonzeros RESIDENT over ceil(class / 384) four-wave workgroups (lane_eval.hpp, TM_) ----------
 def test_lane_team_rows_vs_oracle_repeatable_and_planned(tmp_path):
     """Default thresholds: the rows of 700 .. 5000 nonzeros take lane teams of 2 .. 11 workgroups (M = ceil(class / 384)), the 9000-nonzero row a giant
-    team, the short ones the resident one-CU instances.  Against the oracle (TNC's own stopping tolerance, see above), three runs the same bits."""
+    team, the short ones the resident one-CU instances.  Against the oracle (SURVEY 8c's 1e-5 or 2 x the reference's own spread on this problem under other summation orders, see above), three runs the same bits."""
     res, plan, _ = run_child(tmp_path, "lt", {}, k=100, prec=False, repeat=3, lane_teams=True)
     if not NO_TEAMS and not os.environ.get("POISMF_HIP_NO_LANE_TEAMS") and not os.environ.get("POISMF_HIP_NO_LANE"):
         assert "half_sweep_lane_team_kernel<double,tncg,KS=50,V=1,L=0+32,NW=4,M=2>" in plan, plan
@@ -148,14 +164,13 @@ def test_lane_team_rows_vs_oracle_repeatable_and_planned(tmp_path):
     csr, csc, A0, B0 = ragged_problem(LENGTHS, 12000, 100, False, seed=33)
     l2, _, _ = harness.auto_defaults("tncg", 100)
     args = dict(l2_reg=l2, l1_reg=0.0, w_mult=1.0, step_size=1e-7, limit_step=True, niter=2, maxupd=1500, early_stop=True, reuse_prev=False)
-    Ar, Br = oracle_run(False, csr, csc, A0, B0, "tncg", args)
+    Ar, Br, orf, self_var = H.tncg_yardstick(False, csr, csc, A0, B0, args)
     nA = A0.size
     A, B = res[0][:nA].reshape(A0.shape), res[0][nA:].reshape(B0.shape)
     assert np.isfinite(A).all() and A.min() >= 0 and not A[-1].any()
     og = harness.poisson_objective(A, B, csr, l2, 0.0, 1.0)
-    orf = harness.poisson_objective(Ar, Br, csr, l2, 0.0, 1.0)
-    print(f"lane teams k=100: objective gpu {og:.10g} checker {orf:.10g} rel {abs(og - orf) / abs(orf):.3g}")
-    assert abs(og - orf) <= 5e-4 * abs(orf)
+    print(f"lane teams k=100: objective gpu {og:.10g} checker {orf:.10g} rel {abs(og - orf) / abs(orf):.3g} (reference flavours among themselves {self_var:.3g})")
+    assert abs(og - orf) <= H.tncg_bound(self_var) * abs(orf), (abs(og - orf) / abs(orf), self_var)
 
 
 def test_lane_team_sums_match_the_streamed_path(tmp_path):
@@ -174,7 +189,20 @@ def test_a_lane_team_that_gives_up_is_rerun_on_the_streamed_kernel(tmp_path):
     if NO_TEAMS or os.environ.get("POISMF_HIP_NO_LANE_TEAMS") or os.environ.get("POISMF_HIP_NO_LANE"):
         pytest.skip("no lane-team launches under this knob")
     gave, _, err = run_child(tmp_path, "gave_up", {"POISMF_HIP_TEAM_SPIN_LIMIT": "1"}, k=100, lane_teams=True)
+    n_gave = LAST_UNCHANGED
     one, _, _ = run_child(tmp_path, "one", {"POISMF_HIP_NO_LANE_TEAMS": "1", "POISMF_HIP_NO_GIANT_TEAMS": "1"}, k=100)
     assert "re-run on the streamed path" in err, err
     assert np.isfinite(gave).all()
     assert np.array_equal(gave, one)
+    assert n_gave == LAST_UNCHANGED and n_gave > 0, (n_gave, LAST_UNCHANGED)   # (the early-stop statistic: counted once)
+
+
+def test_team_rows_are_counted_once_in_the_early_stop_statistic(tmp_path):
+    """healthy team launches: their tally reaches the half's counter through the fold kernel -- the same count as without teams"""
+    if NO_TEAMS or os.environ.get("POISMF_HIP_NO_LANE_TEAMS") or os.environ.get("POISMF_HIP_NO_LANE"):
+        pytest.skip("no lane-team launches under this knob")
+    run_child(tmp_path, "teams", {}, k=100, lane_teams=True)
+    n_team = LAST_UNCHANGED
+    run_child(tmp_path, "one", {"POISMF_HIP_NO_LANE_TEAMS": "1", "POISMF_HIP_NO_GIANT_TEAMS": "1"}, k=100)
+    print(f"rows unchanged by a third half-sweep: {n_team} with teams, {LAST_UNCHANGED} without")
+    assert n_team > 0 and abs(n_team - LAST_UNCHANGED) <= 1   # (a row at the 1e-4 threshold may fall either way between two summation orders)
