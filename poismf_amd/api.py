@@ -153,9 +153,12 @@ def release_cache(use_float=None):
 def set_device_cache_mb(mb, use_float=None):
     """Opt in (mb > 0) to / out (0, the default) of keeping released device arrays for the next call: the reference frees everything
     before run_poismf returns (ref src/poismf.c:610-619) and so does this library unless told otherwise here or through
-    POISMF_HIP_DEVICE_CACHE_MB.  Returns {flavour: previous limit in MB}.  use_float = None: both Python flavours (loaded if need be)."""
-    keys = (False, True) if use_float is None else (("r" if use_float == "r" else bool(use_float)),)
-    return {k_: int(load_library(k_).poismf_hip_set_device_cache_mb(int(mb))) for k_ in keys}
+    POISMF_HIP_DEVICE_CACHE_MB.  Returns {flavour: previous limit in MB}.  use_float = None: every flavour ALREADY loaded in this process (as
+    release_cache does; nothing is loaded -- or built -- for the sake of a limit); a named flavour is loaded if need be."""
+    if use_float is None:
+        return {k_: int(lib.poismf_hip_set_device_cache_mb(int(mb))) for k_, lib in list(_LIBS.items())}
+    key = "r" if use_float == "r" else bool(use_float)
+    return {key: int(load_library(key).poismf_hip_set_device_cache_mb(int(mb)))}
 
 
 def _ptr(a):

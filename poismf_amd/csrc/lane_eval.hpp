@@ -44,9 +44,6 @@
 
 namespace pmf {
 
-#ifndef PMF_LANE_PREFETCH
-#define PMF_LANE_PREFETCH 1
-#endif
 // slots per group of the dots' software pipeline (eval(): the point and the LDS sets' slots of the NEXT group are requested before
 // the current group's multiply-adds: 2 x GQ x (1 + LDS sets) 16-byte values in flight).  Five where registers allow it; the instances
 // with two AGPR sets are at 512 registers, and the buffers of five-slot groups were what sent them to scratch (round 3: 68 / 96 / 96 /
@@ -111,11 +108,6 @@ __device__ __forceinline__ unsigned acc_get(unsigned a)
 
 // SMALL_: one staging buffer, shared with the transpose scratch (14 KB of LDS per wave: eight waves per CU, two per SIMD, for
 // kernels whose registers allow that -- one set in architectural registers, nothing in AGPRs)
-// PF_: while a row is being solved, the NEXT row's whole tile (and its values) is requested into accumulator registers that
-// nothing else uses (global_load_dwordx4 straight into AGPR quads, lane by lane as the direct loads of gather()); the switch to
-// the next row is then 200 v_accvgpr_reads and 25 ds_write_b128 instead of a trip to memory.  A row's gather runs at the
-// fabric's gather ceiling (C3: 40 GB per half = 6.7 ms at 6 TB/s) and, at one wave per SIMD, nothing else overlapped it: it
-// was a third of the half.  (One architectural set + one LDS set, one wave per row: what rows of 65 .. 128 nonzeros take.)
 // LP_: a further, PARTIAL set of LP_ (16) nonzeros per wave in LDS (lanes >= LP_ of that set alias lanes < LP_ with a zero
 // coefficient), and the transposing reduction's scratch used in two halves -- what makes rows of 1025 .. 1088 nonzeros fit ONE
 // CU: 4 waves x (64 + 128 + 64 + 16) nonzeros, 155 KB of LDS.
@@ -129,7 +121,7 @@ __device__ __forceinline__ unsigned acc_get(unsigned a)
 // nothing per dimension, the reference's own summation order.  The dots read the same image (lane j its own row, one ds_read_b128
 // per slot, row stride 816 bytes = conflict-free), so NO tile lives in registers: the solver's state has the 256 architectural
 // registers to itself and the v_accvgpr traffic is gone.  TX_ = rows of the image: 48 (39 KB: four rows per CU) or 64 (52 KB: three).
-template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, bool PF_ = false, int LP_ = 0, int TX_ = 0, bool TM_ = false> struct LaneEval {
+template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool SMALL_ = false, int LP_ = 0, int TX_ = 0, bool TM_ = false> struct LaneEval {
     using SA = typename Slot<T>::A;
     static constexpr int SN = Slot<T>::N;                 // elements per 16-byte slot
     static constexpr int KP = KS * SN;                    // elements of a factor row, padded to whole slots
@@ -137,13 +129,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     static constexpr int LP = LP_;                                                  // nonzeros of the partial LDS set (0: none)
     static constexpr int LLT = LL_ + (LP_ > 0 ? 1 : 0);                              // sets read from LDS (the partial one last)
     static constexpr int LV = LV_, LA = LA_, LL = LL_, LR = LV_ + LA_, LT = LV_ + LA_ + LLT;   // sets: VGPR, AGPR, LDS
-    static_assert(LP_ == 0 || (LP_ < WAVE && ((LP_ & (LP_ - 1)) == 0 || 2 * LP_ >= WAVE)), "a partial set: fewer nonzeros than lanes, the last set of the wave");
+    static_assert(LP_ == 0 || ((LP_ & (LP_ - 1)) == 0 && LP_ < WAVE), "a partial set: a power of two of nonzeros, the last set of the wave");
     // the row of the partial set's image that lane l reads: its own below LP, an earlier lane's (finite data, coefficient 0) from there on
-    static __device__ __forceinline__ int part_row(int l)
-    {
-        if constexpr (LP_ > 0 && (LP_ & (LP_ - 1)) == 0) return l & (LP_ - 1);
-        else return l < LP_ ? l : l - LP_;   // (LP_ >= 32: l - LP_ < LP_)
-    }
+    static __device__ __forceinline__ int part_row(int l) { return l & (LP_ - 1); }
     static constexpr int L = LT, NW = NW_, M = 1;
     static constexpr int W = KS < 13 ? KS : 13;           // slots per staged chunk (row stride of the LDS image: 13 slots = 52 banks, conflict-free b128 reads)
     static constexpr int NCH = (KS + W - 1) / W;          // chunks per factor row; chunk c starts at slot min(c W, KS - W)
@@ -151,29 +139,11 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #ifndef PMF_LANE_DIRECT
 #define PMF_LANE_DIRECT 1   // the sets in architectural registers are loaded lane by lane, without staging (gather())
 #endif
-#ifndef PMF_LANE_DIRECT_A
-#define PMF_LANE_DIRECT_A 0   // The AGPR sets loaded straight into their registers as well (inline-asm global_load into "=a" operands: one trip
-                              // to memory per row instead of a pipeline of staged chunks).  NOT adopted, and not safe as it stands: hipcc
-                              // regards an asm output as written when the statement ends, and in the (1, 2, 1) instances -- 512 registers
-                              // in use -- it SPILLS the 200 freshly "loaded" values to scratch right behind the loads, before the data has
-                              // landed (1.6 KB of scratch per lane, wrong tiles).  The staged path writes the same registers with
-                              // v_accvgpr_write from data that is there.
-#endif
-#ifndef PMF_LANE_STAGE_V
-#define PMF_LANE_STAGE_V 0   // instances with AGPR sets stage the VGPR set through LDS as well (fewer tag look-ups, one more round trip): C3 B half 18.8 -> 18.7 ms, within noise; off
-#endif
-    static constexpr bool DIRECT_V = PMF_LANE_DIRECT && !(PMF_LANE_STAGE_V && LA_ > 0 && sizeof(T) == 8);
-    static constexpr bool DIRECT_A = DIRECT_V && PMF_LANE_DIRECT_A;
-#ifndef PMF_LANE_TEMP_A
-#define PMF_LANE_TEMP_A 0   // the AGPR sets by plain per-lane loads into architectural registers (free between two rows: the solver's state is
-                            // dead) and v_accvgpr_write from there -- no staging buffers, so the LDS sets' DMA is requested FIRST and is in
-                            // flight together with the register sets': two trips to memory per row instead of three.  Measured, C3 B half,
-                            // the 78.7 k rows of <= 1024 nonzeros: 13.2 -> 15.6 ms (maxupd 1: 7.3 -> 9.6).  A per-lane load instruction names
-                            // 64 different factor rows -- 64 tag look-ups in the texture path -- where a DMA chunk instruction covers five
-                            // (13 adjacent lanes per row): the gather is bound by look-ups, not by round trips.  Off.
-#endif
-    static constexpr bool TEMP_A = PMF_LANE_TEMP_A && DIRECT_V && !DIRECT_A && LA_ > 0;
-    static constexpr bool STAGED = LL_ > 0 || (LA_ > 0 && !DIRECT_A && !TEMP_A) || !DIRECT_V;   // some set travels through LDS
+    static constexpr bool DIRECT_V = PMF_LANE_DIRECT;
+    // (measured and gone in round 6: the AGPR sets loaded straight into their registers by inline asm -- unsafe, hipcc spills "loaded" values before
+    // the data has landed; AGPR sets through free VGPRs -- C3 B half 13.2 -> 15.6 ms, a per-lane load names 64 rows = 64 tag look-ups; the VGPR set of
+    // the AGPR instances staged through LDS -- within noise.  DESIGN.md 4.4 keeps the numbers.)
+    static constexpr bool STAGED = LL_ > 0 || LA_ > 0 || !DIRECT_V;   // some set travels through LDS
     static constexpr int NBUF = LL_ > 0 ? LL_ * NCH : (!STAGED ? 0 : (SMALL_ ? 1 : 2));  // staging buffers; the chunks of the LDS sets stay in theirs
     static constexpr bool ALIAS = SMALL_ && NBUF > 0 && LL_ == 0;   // (with an LDS set the buffers hold the tile: the scratch gets its own bytes)
     static_assert(KP % NC == 0, "blocks of equal size");
@@ -203,11 +173,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
 #ifndef PMF_LANE_COAL
 #define PMF_LANE_COAL 1
 #endif
-#ifdef PMF_ABLATE_DOTS
-#define PMF_ABLATE_DOTS_ON 1
-#else
-#define PMF_ABLATE_DOTS_ON 0
-#endif
     // COAL (round 4; with XPOSE): the register sets are fetched by COALESCED loads -- instruction i of a set reads the 64 consecutive
     // 16-byte slots 64 i .. 64 i + 63 of the row-major image [nonzero][W slots], i.e. W adjacent lanes share a factor row, as the
     // LDS-DMA chunks do -- straight into the tile's own registers (all sets of a row in flight at once), and each set is then turned
@@ -217,17 +182,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     // of round 4 put the gather of a 1000-nonzero fp32 row at 26 k of its 62 k cycles.
     static constexpr bool COAL = PMF_LANE_COAL && XPOSE && LA_ == 0 && PMF_LANE_DIRECT;
     static_assert(!COAL || (STAGE_BYTES <= KS * XP_QS * 16 && KS == W), "a whole set's image fits the reduction's image");
-#ifndef PMF_LANE_FIVE
-#define PMF_LANE_FIVE 0   // doubles, one VGPR set + one LDS set, one wave per row: the scratch in two halves brings a wave's LDS from 36.3 to 31.1 KB,
-                          // i.e. FIVE rows per CU instead of four, one SIMD taking two waves.  Measured, C3 A half: 19.8 -> 23.9 ms (maxupd 1:
-                          // 10.0 -> 14.1): CG's instance needs 256 VGPRs + 44 AGPRs as it is, and held to 256 registers it spills 172 bytes
-                          // per lane into the evaluation loops -- a fifth row does not pay for that.  Off.
-#endif
-    static constexpr bool FIVE = PMF_LANE_FIVE && sizeof(T) == 8 && LV_ == 1 && LA_ == 0 && LL_ == 1 && NW_ == 1 && !PF_ && LP_ == 0;
-    static constexpr int RED_PH = (LP_ > 0 || FIVE) ? 2 : 1;        // the columns pass through the scratch in this many groups
+    static constexpr int RED_PH = LP_ > 0 ? 2 : 1;        // the columns pass through the scratch in this many groups
     static constexpr int RED_COLS = RED_PH == 1 ? 16 : (CW + 1) / 2;
     static constexpr int TX = TX_;
-    static_assert(TX_ == 0 || (LV_ == 1 && LA_ == 0 && LL_ == 0 && LP_ == 0 && NW_ == 1 && !PF_ && !SMALL_ && sizeof(T) == 8 && TX_ % 4 == 0 && TX_ <= WAVE),
+    static_assert(TX_ == 0 || (LV_ == 1 && LA_ == 0 && LL_ == 0 && LP_ == 0 && NW_ == 1 && !SMALL_ && sizeof(T) == 8 && TX_ % 4 == 0 && TX_ <= WAVE),
                   "the LDS image of the tile: doubles, one register set, one wave per row");
     // (row-major [TX][KS + 1 slots]: the gradient reads ALONG a row -- conflict-free whatever the stride --, the dots and the image's writes
     // go DOWN a column, lane = row: a stride of 51 slots = 204 banks puts the 16 lanes of a ds_read_b128 service group on 16 different
@@ -274,13 +232,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     UE tae[LA > 0 ? LA : 1][KP];   // the sets in accumulator registers, one AGPR (pair) per element (AGPR-class values: written by
                                    // acc_put or by a load straight into them, read by acc_get only).  (Quads per 16-byte slot, filled by
                                    // dwordx4 loads, cost the allocator 1.7 KB of scratch per lane: 128-bit tuples fragment the file.)
-    static constexpr bool PREFETCH = PF_;
-    static_assert(!PF_ || (LV_ == 1 && LA_ == 0 && LL_ == 1 && NW_ == 1 && sizeof(T) == 8 && PMF_LANE_DIRECT), "prefetch: one register set + one LDS set, one wave");
-    typedef unsigned U2 __attribute__((ext_vector_type(2)));
-    U4 pfq[PF_ ? 2 * KS : 1];   // AGPR-class: the next row's slots, [0, KS) of its first 64 nonzeros, [KS, 2 KS) of the rest
-    U2 pfx[PF_ ? 2 : 1];        // AGPR-class: the next row's values
-    U2 pfm[PF_ ? NC : 1];       // AGPR-class: the next row's starting point (its row of the factor being updated)
-    T xt[NC];                   // the current row's starting point, as take_prefetched left it
     T xcur;              // SPOINT: the current point, element of this lane's dimension (0 in lanes that hold none)
     T xr[LT];            // x_j of this lane's nonzeros
     unsigned idx_n[LT];  // column indices of the row whose tile is requested next (fetch_meta -> gather)
@@ -358,93 +309,8 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
     }
     __device__ __forceinline__ unsigned* ticket_slot() const { return ticket_word; }
 
-    // ---- prefetch of the next row (PF_; driven by sweep_rows_pf in poismf_hip.hip, ONE call site each: the AGPR-class values
-    // are loop-carried, and every further place that defines them costs a register-to-register copy of all 204) ------------
-    // (plain recursion, here and in acc_load_set: a variable that appears only as an asm operand inside a generic lambda is not
-    // captured by hipcc)
-    template <int S2, int C = 0> __device__ __forceinline__ void acc_load_set(const char* base)
-    {
-        if constexpr (C < KP) {
-            if constexpr (sizeof(T) == 8) asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=a"(tae[S2][C]) : "v"(base), "i"(C * 8));
-            else asm volatile("global_load_dword %0, %1, off offset:%2" : "=a"(tae[S2][C]) : "v"(base), "i"(C * 4));
-            acc_load_set<S2, C + 1>(base);
-        }
-    }
-    template <int S2, int Q = 0> __device__ __forceinline__ void pf_load_set(const char* base)
-    {
-        if constexpr (Q < KS) {
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(pfq[S2 * KS + Q]) : "v"(base), "i"(Q * 16));
-            pf_load_set<S2, Q + 1>(base);
-        }
-    }
-    template <int I> __device__ __forceinline__ void pf_load_m(const T* xp)
-    {
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(pfm[I]) : "v"(xp));
-    }
-    template <int S2> __device__ __forceinline__ void pf_load_x(const T* xp)
-    {
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(pfx[S2]) : "v"(xp));
-    }
-    // The tile of the row whose indices fetch_meta requested last (idx_n), and its values (val, nnz_row of them).  Inline asm:
-    // hipcc has no way to load into AGPRs, and these loads must stay in flight while the solver runs -- the only wait for them is
-    // the explicit one in take_prefetched().  (hipcc's own counted waits can only over-wait because of them: memory returns in order.)
-    // (mrow: the row's current values in the factor being updated -- the solver's starting point)
-    __device__ __forceinline__ void prefetch_issue_row(const T* val, unsigned nnz_row, const T* mrow)
-    {
-        if constexpr (PF_) {
-            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
-            static_for<0, 2>([&](auto sc) {
-                constexpr int s2 = decltype(sc)::value;
-                pf_load_set<s2>((const char*)F + (size_t)__umul24(idx_n[s2], rowbytes));
-                const unsigned j = (unsigned)(WAVE * s2 + lane);
-                pf_load_x<s2>(val + (j < nnz_row ? j : 0u));
-            });
-            static_for<0, NC>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                pf_load_m<i>(mrow + (act[i] ? elem[i] : 0));
-            });
-        }
-    }
-    // solve_row: the point the row starts from (engines without prefetch load it here)
-    __device__ __forceinline__ void start_point(const T* mrow, T (&x)[NC]) const
-    {
-        if constexpr (PF_) {
-#pragma unroll
-            for (int i = 0; i < NC; i++) x[i] = xt[i];
-        } else load_vec(mrow, x);
-    }
-    // the prefetched row becomes the current one
-    __device__ __forceinline__ void take_prefetched(unsigned nnz_row)
-    {
-        if constexpr (PF_) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            nnz = nnz_row;
-            static_for<0, KS>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                t[0][q * SN] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[q][1]) << 32) | acc_get(pfq[q][0]));
-                t[0][q * SN + 1] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[q][3]) << 32) | acc_get(pfq[q][2]));
-            });
-            static_for<0, KS>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                constexpr int c = slot_chunk(q);
-                SA v;
-                v.v[0] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[KS + q][1]) << 32) | acc_get(pfq[KS + q][0]));
-                v.v[1] = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfq[KS + q][3]) << 32) | acc_get(pfq[KS + q][2]));
-                *((SA*)(stage + c * STAGE_BYTES) + lane * W + (q - chunk_start(c))) = v;
-            });
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                const T xv = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfx[s2][1]) << 32) | acc_get(pfx[s2][0]));
-                xr[s2] = (unsigned)(WAVE * s2 + lane) < nnz ? xv : (T)0;
-            }
-#pragma unroll
-            for (int i = 0; i < NC; i++) {
-                const T mv = __builtin_bit_cast(T, ((unsigned long long)acc_get(pfm[i][1]) << 32) | acc_get(pfm[i][0]));
-                xt[i] = act[i] ? mv : (T)0;
-            }
-            wave_lds_fence();
-        }
-    }
+    // solve_row: the point the row starts from
+    __device__ __forceinline__ void start_point(const T* mrow, T (&x)[NC]) const { load_vec(mrow, x); }
 
     // ---- k-vectors: lane <-> dimension -------------------------------------------------------------------------------
     // Several wave-wide sums at once (the solvers' dot products come in groups: theta / beta / |g|^2; g.d / d.d; the three
@@ -592,7 +458,7 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         // KS loads in flight per lane, no staging, no address arithmetic beyond the row's base.  (64 different rows per
         // instruction: the price is in the texture unit -- 64 tag look-ups per instruction -- which a row pays once; the lines
         // are the same 2-4 per row that a coalesced fetch would bring.)
-        constexpr int S0 = DIRECT_V ? ((DIRECT_A || TEMP_A) ? LR : LV) : 0;   // first set that goes through the staging buffers
+        constexpr int S0 = DIRECT_V ? LV : 0;   // first set that goes through the staging buffers
         auto request_lds_sets = [&]() {
             static_for<0, LL * NCH>([&](auto wc) {
                 constexpr int w = decltype(wc)::value;
@@ -605,7 +471,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 });
             }
         };
-        if constexpr (TEMP_A && LL > 0) request_lds_sets();   // nothing is staged: their buffers are free now
         if constexpr (COAL) {
             const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
             // (the W (row, slot) pairs of a lane are the same for every row of the launch; derived from an opaque copy of the lane
@@ -694,39 +559,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 });
             });
         }
-        // Sets in accumulator registers: the same loads, straight into the AGPR quads (inline asm: hipcc cannot address AGPRs;
-        // it does not count these loads either -- the explicit vmcnt(0) below is their wait).  All sets of a row are in flight
-        // together: one trip to memory per row where a staged pipeline of chunks made four.
-        if constexpr (DIRECT_A && LA > 0) {
-            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
-            static_for<0, LA>([&](auto sc) {
-                constexpr int s2 = decltype(sc)::value;
-                acc_load_set<s2>((const char*)F + (size_t)__umul24(idx[LV + s2], rowbytes));
-            });
-        }
-        if constexpr (TEMP_A) {
-            const unsigned rowbytes = (unsigned)ldF * (unsigned)sizeof(T);
-            static_for<0, LA>([&](auto sc) {
-                constexpr int s2 = decltype(sc)::value;
-                const char* base = (const char*)F + (size_t)__umul24(idx[LV + s2], rowbytes);
-                typename Slot<T>::U tmp[KS];
-                static_for<0, KS>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    tmp[q] = *(const typename Slot<T>::U*)(base + q * 16);
-                });
-                static_for<0, KS>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-#pragma unroll
-                    for (int e = 0; e < SN; e++) {
-                        if constexpr (sizeof(T) == 8) {
-                            const unsigned long long b = __builtin_bit_cast(unsigned long long, tmp[q].v[e]);
-                            tae[s2][q * SN + e][0] = acc_put((unsigned)b);
-                            tae[s2][q * SN + e][1] = acc_put((unsigned)(b >> 32));
-                        } else tae[s2][q * SN + e][0] = acc_put(__builtin_bit_cast(unsigned, tmp[q].v[e]));
-                    }
-                });
-            });
-        }
         // (without direct loads) the register sets' chunks pass through the staging buffers, NBUF in flight
         constexpr int NWORK = (LR - S0) * NCH;
         constexpr int DEPTH = NBUF < NWORK ? NBUF : NWORK;
@@ -750,11 +582,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                 dma_chunk<chunk_start(w2 % NCH)>(idx[S0 + w2 / NCH], w % NBUF);
             }
         });
-        if constexpr (DIRECT_A && LA > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (ALIAS) { __builtin_amdgcn_s_waitcnt(0xc07f); wave_lds_fence(); }   // the scratch of the reductions is this buffer
         // LDS sets: their chunks stay in the buffers (set u, chunk c in buffer u NCH + c)
         if constexpr (LL > 0 || LP > 0) {
-            if constexpr (!(TEMP_A && LL > 0) && !(COAL && LP > 0)) request_lds_sets();
+            if constexpr (!(COAL && LP > 0)) request_lds_sets();
             wait_dma<0>();
         }
     }
@@ -875,17 +706,9 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                              // always done (reg_eval.hpp): PG(10) item rows 3.45 -> 3.15 ms.  (The instances of fewer sets read the point from LDS: packed there
                              // too, TNCG fp32 110.8 -> 109.9 ms, CG fp32 18.3 -> 18.0 for another order of their sums -- not kept.)
 #endif
-#ifndef PMF_LANE_BPERM32
-#define PMF_LANE_BPERM32 0   // measured: PG item rows 4.86 -> 5.19 ms, C2 CG fp32 2.20 -> 2.97, TNCG fp32 12.6 -> 17.2: the round trip sits in every dependent chain of the reduction
-#endif
     template <int W_> __device__ __forceinline__ T fold(T a, T b) const
     {
-        if constexpr (sizeof(T) == 4 && PMF_LANE_BPERM32) {
-            const bool up = (lane & W_) != 0;
-            const T send = up ? a : b, mine = up ? b : a;
-            const int got = __builtin_amdgcn_ds_bpermute((lane ^ W_) * 4, __builtin_bit_cast(int, send));
-            return mine + __builtin_bit_cast(T, got);
-        } else return swap_fold<W_>(a, b);
+        return swap_fold<W_>(a, b);   // (the folds through the LDS crossbar, ds_bpermute + two selects, lost everywhere: DESIGN.md 4.4)
     }
     // the two dimensions COL + CW R0 (kept by the lanes of the lower half-wave) and COL + CW (R0 + 2) (upper) of block B
     template <int B, int COL, int R0> __device__ __forceinline__ T level_a(const T (&coef)[LT], const T (&tl)[4][LLX]) const
@@ -904,13 +727,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
             // the four rows' sums of the (up to) four batches meet in two swap folds: row r ends up with batch r, i.e. lane l with the
             // total of dimension l.  ~160 VALU instructions for 52 dimensions, dependent chains of six operations.
             static_assert(B == 0 && KP <= WAVE, "one element per lane");
-#ifdef PMF_ABLATE_REDUCE   // development: what a pass costs WITHOUT the reduction (wrong results, same control flow)
-            {
-                T u = coef[0] * t[0][0];
-                static_for<1, LV>([&](auto sc) { u = fma_t(coef[decltype(sc)::value], t[decltype(sc)::value][decltype(sc)::value], u); });
-                return u;
-            }
-#endif
             const bool c8 = (lane & 8) != 0, c4 = (lane & 4) != 0, c2 = (lane & 2) != 0, c1 = (lane & 1) != 0;
             constexpr int NBATCH = (KP + 15) / 16;
             T rowsum[4] = { (T)0, (T)0, (T)0, (T)0 };
@@ -1185,8 +1001,6 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
         if constexpr (FROM_CACHE) {
 #pragma unroll
             for (int s = 0; s < LT; s++) pred[s] = pv[s];
-        } else if constexpr (SPOINT && PMF_ABLATE_DOTS_ON) {   // development: what a pass costs WITHOUT the dots
-            static_for<0, LT>([&](auto sc) { constexpr int s2 = decltype(sc)::value; pred[s2] = fma_t(t[s2][s2], xcur, (T)1); });
         } else if constexpr (SPOINT) {
             // dimension c of the point sits in lane (c % CW) + 16 (c / CW) (XPOSE: in lane c): one v_readlane, then a scalar operand of LT multiply-adds
             // (read in groups of GS ahead of their use: a v_readlane's SGPR needs two wait states before a VALU may read it)

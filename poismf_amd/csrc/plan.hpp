@@ -164,16 +164,13 @@ int regw_steps_for(unsigned max_nnz, int nw)
 // Two CUs where they hold the row; the 28-step instance (no scratch) where three are needed anyway.
 // Below TEAM_MIN_NNZ a row's tile (k = 50 fp64: 400 B per nonzero) is resident in one CU's LDS: the LDS engine keeps it.
 constexpr unsigned TEAM_MIN_NNZ = 385;
-#ifndef PMF_TEAM_S36
-#define PMF_TEAM_S36 1
-#endif
 struct TeamShape { int members, steps; };
 inline TeamShape team_shape_for(unsigned max_nnz)
 {
     const unsigned per_step = (unsigned)(REG_JG * TEAM_NW);
     if (max_nnz < TEAM_MIN_NNZ) return { 0, 0 };
     if (max_nnz <= 2u * 32u * per_step) return { 2, 32 };
-    if (PMF_TEAM_S36 && max_nnz <= 2u * 36u * per_step) return { 2, 36 };
+    if (max_nnz <= 2u * 36u * per_step) return { 2, 36 };
     if (max_nnz <= 3u * 28u * per_step) return { 3, 28 };
     if (max_nnz <= 3u * 32u * per_step) return { 3, 32 };
     if (max_nnz <= 4u * 32u * per_step) return { 4, 32 };
@@ -187,14 +184,6 @@ inline TeamShape team_shape_for(unsigned max_nnz)
 // lv / la / ll: lane sets per wave in architectural registers / accumulator registers / LDS; waves: per row; small: the two-waves-per-SIMD flavour (a few KB
 // of LDS per wave); lp: nonzeros of a further, partial LDS set; tx: rows of the LDS image the gradient is accumulated from (lane_eval.hpp, TX_)
 struct LaneShape { int lv, la, ll, waves; int small; int lp = 0; int tx = 0; };
-#ifndef PMF_LANE_A2
-#define PMF_LANE_A2 0   // doubles, rows of 65 .. 128 nonzeros: 1 = two waves of one register set each, two waves per SIMD; 0 = one wave, second set in LDS
-                        // (measured, C3 A half, CG fp64: 22.3 ms against 20.0 -- the barrier per evaluation and the second copy of the
-                        // solver's chain cost more than the second wave per SIMD hides)
-#endif
-#ifndef PMF_LANE_F32
-#define PMF_LANE_F32 1
-#endif
 inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
 {
     if (sizeof(real_t) == 8) {
@@ -202,15 +191,11 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
         if (s_load == 25) {          // a set is 100 registers / 25.6 KB of LDS
             if (cls <= 64) return { 1, 0, 0, 1, 1 };
             // 65 .. 96 nonzeros (round 5; a third of config C3's user rows): one register set + a PARTIAL LDS set of 32 -- 18.8 KB of LDS per row
-            // instead of the 36 KB of a full LDS set: eight rows per CU, two waves per SIMD (POISMF_HIP_K50_P32=0: off)
-            static const bool k50_p32 = getenv("POISMF_HIP_K50_P32") == nullptr || atoi(getenv("POISMF_HIP_K50_P32")) != 0;
-            if (cls <= 96 && k50_p32 && method != POISMF_TNCG) return { 1, 0, 0, 1, 1, 32 };
-            // 97 .. 112 nonzeros (round 6; half of C3's user rows: Poisson(100)): the partial set with 48 nonzeros -- 26 KB of LDS per row, SIX rows per
-            // CU (two SIMDs take two waves) where the full LDS set's 36 KB allow four (POISMF_HIP_K50_P48=0: off)
-            static const bool k50_p48 = getenv("POISMF_HIP_K50_P48") == nullptr || atoi(getenv("POISMF_HIP_K50_P48")) != 0;
-            if (cls <= 112 && k50_p32 && k50_p48 && method != POISMF_TNCG) return { 1, 0, 0, 1, 1, 48 };
-            static const int k50_mid = getenv("POISMF_HIP_K50_MID") ? atoi(getenv("POISMF_HIP_K50_MID")) : (PMF_LANE_A2 ? 2 : 1);   // experiment knob (round 6)
-            if (cls <= 128) return k50_mid == 2 ? LaneShape{ 1, 0, 0, 2, 1 } : LaneShape{ 1, 0, 1, 1, 0 };
+            // instead of the 36 KB of a full LDS set: eight rows per CU, two waves per SIMD
+            if (cls <= 96 && method != POISMF_TNCG) return { 1, 0, 0, 1, 1, 32 };
+            // (97 .. 112 nonzeros on a partial set of 48 -- six rows per CU instead of the full LDS set's four -- and 65 .. 128 on two waves of one register
+            // set each were measured in round 6: 12.59 / 12.66 ms against 12.63 for the A half's 626 801 such rows of C3, DESIGN.md 6.0c: not kept)
+            if (cls <= 128) return LaneShape{ 1, 0, 1, 1, 0 };
             if (cls <= 256) return { 1, 2, 1, 1, 0 };
             if (cls <= 512) return { 1, 2, 1, 2, 0 };
             if (cls <= 1024) return { 1, 2, 1, 4, 0 };
@@ -218,53 +203,30 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
         } else if (s_load == 50) {   // a set is 200 registers / 51 KB of LDS
             // rows of at most 64 nonzeros: the gradient from a second, row-major copy of the tile in LDS instead of the transposing
             // reduction (lane_eval.hpp, TX_): 39 KB of LDS for up to 48 nonzeros (four rows per CU), 52 KB up to 64 (three).
-            // POISMF_HIP_NO_TX=1: the reduction (rounds 3-4)
-            static const bool no_tx = getenv("POISMF_HIP_NO_TX") != nullptr;
-            static const unsigned tx_max = getenv("POISMF_HIP_TX_MAX") ? (unsigned)atoi(getenv("POISMF_HIP_TX_MAX")) : 64u;   // tuning knob: 48 = the image for rows of at most 48 nonzeros only
-            if (cls <= 48 && !no_tx) return { 1, 0, 0, 1, 0, 0, 48 };
-            if (cls <= 64 && cls <= tx_max && !no_tx) return { 1, 0, 0, 1, 0, 0, 64 };
-            if (cls <= 64) return { 1, 0, 0, 1, 0 };
-            // (two such rows per CU: config C5's user rows of 65 .. ~95 nonzeros leave the streamed path; tuning knob
-            // POISMF_HIP_K100_LANE_MAX=<64|128>)
-            static const unsigned k100_max = getenv("POISMF_HIP_K100_LANE_MAX") ? (unsigned)atoi(getenv("POISMF_HIP_K100_LANE_MAX")) : 384u;
-            // 65 .. 128 nonzeros: one register set + one LDS set on one wave takes 63 KB of LDS -- two rows per CU, two of its four SIMDs idle;
-            // two waves of one register set each (no LDS set) keep all four busy on the same two rows (POISMF_HIP_K100_MID=1: the one-wave
-            // instance of rounds 4-5a)
-            static const int k100_mid = getenv("POISMF_HIP_K100_MID") ? atoi(getenv("POISMF_HIP_K100_MID")) : 2;
-            if (cls <= 128 && cls <= k100_max) return k100_mid == 2 ? LaneShape{ 1, 0, 0, 2, 0 } : LaneShape{ 1, 0, 1, 1, 0 };
+            // (the transposing reduction for these rows -- rounds 3-4, POISMF_HIP_NO_TX -- and the image for 48 nonzeros only went in round 6)
+            if (cls <= 48) return { 1, 0, 0, 1, 0, 0, 48 };
+            if (cls <= 64) return { 1, 0, 0, 1, 0, 0, 64 };
+            // 65 .. 128 nonzeros: one register set + one LDS set on one wave takes 63 KB of LDS -- two rows per CU, two of its four SIMDs idle
+            // (rounds 4-5a); two waves of one register set each (no LDS set) keep all four busy on the same two rows
+            if (cls <= 128) return LaneShape{ 1, 0, 0, 2, 0 };
             // 129 .. 384 nonzeros (round 5): four waves of one register set + a partial LDS set of 32 nonzeros each, one row per CU: config
             // C5's item rows of this length stay on chip for all of TNC's ~70 evaluations instead of re-streaming 800 bytes per nonzero
             // for each of them (153 x the algorithmic traffic in round 4's streamed launch)
-            if (cls <= 384 && cls <= k100_max) return { 1, 0, 0, 4, 0, 32 };
+            if (cls <= 384) return { 1, 0, 0, 4, 0, 32 };
         }
-    } else if (PMF_LANE_F32 && s_load == 13) {   // floats: a set is 52 registers, every set in architectural registers, two waves per SIMD
+    } else if (s_load == 13) {   // floats: a set is 52 registers, every set in architectural registers, two waves per SIMD
         if (method == POISMF_PG) {
             // PG does the same work on every pass and the slot layout (reg_eval.hpp) is the cheaper one for single-wave rows; what
             // the lane layout buys is the long rows: eight waves with NO cross-lane traffic in the dots and one transposing
             // reduction per wave instead of a butterfly per four-nonzero step
-#ifndef PMF_LANE_PG32
-#define PMF_LANE_PG32 0   // measured, C4 matrix, PG(10) fp32, B half: 9.5 ms against 8.0 ms for reg_eval.hpp's eight-wave kernels: a pass of
-                          // either is ~5 k cycles of barrier / LDS round trips in lockstep, which the cheaper instruction stream does not shorten
-#endif
-#ifndef PMF_LANE_PG_LONG
-#define PMF_LANE_PG_LONG 0
-#endif
-#ifndef PMF_LANE_PG32X4
-#define PMF_LANE_PG32X4 1   // rows of 513 .. 1024 nonzeros on FOUR waves of four sets each (three in registers, one in LDS), two such rows per CU
-#endif
-            if (PMF_LANE_PG32X4 && cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1 };
+            // (a first port -- two or three sets per wave, eight waves per row, PMF_LANE_PG32 / POISMF_HIP_PG_LONG_LANE -- lost to reg_eval.hpp's eight-wave
+            // kernels, 9.5 against 8.0 ms for the B half and 1.93 against 1.83 ms on the rows above 1024; both went in round 6)
+            // rows of 513 .. 1024 nonzeros on FOUR waves of four register sets each, two such rows per CU
+            if (cls > 512 && cls <= 1024) return { 4, 0, 0, 4, 1 };
             // 1025 .. 1088 nonzeros (round 6; 98.6 % of the C4 matrix's item rows above 1024: Poisson(1000)): the same four waves of four register sets
             // + a PARTIAL LDS set of 16 nonzeros per wave (4 KB; 76 KB of LDS per row: still two rows per CU) instead of the register engine's
-            // eight-wave kernel at one row per CU (0.32 of the byte roofline, the worst bucket of the headline).  POISMF_HIP_PG_P16=0: off
-            static const bool pg_p16 = getenv("POISMF_HIP_PG_P16") == nullptr || atoi(getenv("POISMF_HIP_PG_P16")) != 0;
-            if (PMF_LANE_PG32X4 && pg_p16 && cls > 1024 && cls <= 1088) return { 4, 0, 0, 4, 1, 16 };
-            // (1025 .. 1152 nonzeros: 4.5 sets per wave do not fit; six waves x three sets, one row per CU, measured 2.50 ms against 1.85 ms
-            // for reg_eval.hpp's eight-wave kernel on the 21 k such rows of the C4 matrix -- they stay there)
-            if (PMF_LANE_PG32 && cls > 512 && cls <= 1024) return { 2, 0, 0, 8, 1 };
-            // rows of 1025 .. 1536 nonzeros: eight waves of three sets, one row per CU (tuning knob POISMF_HIP_PG_LONG_LANE=0 / 1:
-            // the register engine's eight-wave kernels / this instance)
-            static const int long_lane = getenv("POISMF_HIP_PG_LONG_LANE") ? atoi(getenv("POISMF_HIP_PG_LONG_LANE")) : PMF_LANE_PG_LONG;
-            if ((PMF_LANE_PG32 || long_lane) && cls > 1024 && cls <= 1536) return { 3, 0, 0, 8, 1 };
+            // eight-wave kernel at one row per CU (0.32 of the byte roofline, the worst bucket of round 5's headline: 1.83 -> 1.21 ms, 0.47)
+            if (cls > 1024 && cls <= 1088) return { 4, 0, 0, 4, 1, 16 };
             return { 0, 0, 0, 0, 0 };
         }
         if (cls <= 64) return { 1, 0, 0, 1, 1 };

@@ -232,53 +232,6 @@ __device__ __forceinline__ void sweep_rows(const HalfArgs<T>& a, EV& ev, unsigne
     }
 }
 
-// The row loop of the lane-engine instance that prefetches (lane_eval.hpp, PF_): rows dealt out statically; while row i is being
-// solved, the tile of row i + 1 is in flight into AGPRs and the indices of row i + 2 into registers.  Each of the three steps
-// has ONE call site in the loop.
-template <class EV, class T, int NC, int METHOD>
-__device__ __forceinline__ void sweep_rows_pf(const HalfArgs<T>& a, EV& ev, unsigned char* smem)
-{
-    if (a.gate != nullptr && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-    ev.init(a.geom, a.F, smem);
-    T bs[NC];
-    ev.load_vec(a.bsum, bs);
-    const RowDesc* desc = a.desc + a.perm_begin;
-    const unsigned stride = gridDim.x;
-    auto row_of = [&](unsigned t, unsigned& nnz, unsigned long long& p0, unsigned& lrow) {
-        const RowDesc d = desc[t < a.nrows ? t : 0u];   // (past the end: a valid address and no nonzeros -- the loads fetch the zero row)
-        nnz = t < a.nrows ? uniform(d.nnz) : 0u;
-        p0 = ((unsigned long long)uniform(d.p0_hi) << 32) | uniform(d.p0_lo);
-        lrow = uniform(d.lrow);
-    };
-    auto mrow_of = [&](unsigned lrow) { return a.M + (size_t)(a.row_offset + lrow) * (size_t)a.geom.k; };
-    unsigned t0 = blockIdx.x;
-    if (t0 >= a.nrows) return;
-    unsigned n0, l0, n1, l1, n2, l2;
-    unsigned long long p0, p1, p2;
-    row_of(t0, n0, p0, l0);
-    ev.fetch_meta(a.indices + p0, n0);
-    ev.prefetch_issue_row(a.values + p0, n0, mrow_of(l0));        // the wave's first row takes the same road as every other one
-    unsigned t1 = t0 + stride;
-    row_of(t1, n1, p1, l1);
-    ev.fetch_meta(a.indices + p1, n1);                            // the second row's indices
-    for (;;) {
-        ev.take_prefetched(n0);                                   // (the one wait: the current row's tile, the next row's indices)
-        // Nothing hipcc counts may be waited for between here and the end of the solve except what is issued BEFORE the prefetch
-        // loads: its counted waits cannot see them, and a wait for anything younger would wait for all of them.
-        const unsigned t2 = t1 + stride;
-        row_of(t2, n2, p2, l2);                                   // (descriptor of the row after next: a short trip, consumed at once)
-        ev.prefetch_issue_row(a.values + p1, n1, mrow_of(l1));    // the next row's tile -> AGPRs, in flight during this row's solve
-        ev.fetch_meta(a.indices + p2, n2);                        // the indices of the row after next -> idx_n (consumed one solve later)
-        solve_row<EV, T, NC, METHOD>(a, ev, bs, l0, n0);
-        if (t1 >= a.nrows) break;
-        t0 = t1; n0 = n1; l0 = l1; p0 = p1;
-        t1 = t2; n1 = n2; l1 = l2; p1 = p2;
-    }
-}
-
-#ifndef PMF_TNC_PREFETCH
-#define PMF_TNC_PREFETCH 0
-#endif
 // LDS-tile engine (row_eval.hpp): one wavefront (= one 64-thread workgroup, so no workgroup barrier is ever needed and
 // the LDS tile is private), or NW wavefronts per row for the long-row path.
 template <class T, int NC, int METHOD, int SL, int NW>
@@ -286,15 +239,11 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_kernel(const HalfArgs<T> 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // streamed rows prefetch the next chunk's tile (row_eval.hpp, PF); TNC's register budget is spent already
-#ifdef PMF_FORCE_NO_PF
-    constexpr bool PF = false;
-#else
     // (only in the instances with a compile-time slot count: the generic fp64 CG instance is at 512 registers already,
     // and the 14 slots in flight pushed it into scratch -- and into wrong results on the k = 200 test)
     // (TNC: in the eight-wave long-row instances only -- a row of 1e5 nonzeros is ~800 chunks per evaluation, each a full trip to
     // memory when nothing is requested ahead; the one-wave instances have no registers left for the 14 slots in flight)
-    constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
-#endif
+    constexpr bool PF = SL > 0 && METHOD != K_TNCG;
     RowEval<T, NC, SL, NW, PF> ev;
     if constexpr (NW > 1) {
         if (a.arrive != nullptr && threadIdx.x == 0) atomicAdd(a.arrive, 1u);
@@ -414,7 +363,7 @@ template <class T, int NC, int METHOD, int SL, int NW>
 __global__ __launch_bounds__(WAVE* NW) void half_sweep_giant_kernel(const HalfArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool PF = SL > 0 && (METHOD != K_TNCG || PMF_TNC_PREFETCH);
+    constexpr bool PF = SL > 0 && METHOD != K_TNCG;
     using EV = RowEval<T, NC, SL, NW, PF, true>;
     EV ev;
     team_rows<EV, T, NC, METHOD>(a, ev, smem);
@@ -422,7 +371,7 @@ __global__ __launch_bounds__(WAVE* NW) void half_sweep_giant_kernel(const HalfAr
 template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, int LP>
 __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void half_sweep_lane_team_kernel(const HalfArgs<T> a)
 {
-    using EV = LaneEval<T, KS, LV, LA, LL, NW, false, false, LP, 0, true>;
+    using EV = LaneEval<T, KS, LV, LA, LL, NW, false, LP, 0, true>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
     EV ev;
     team_rows<EV, T, EV::NC, METHOD>(a, ev, smem);
@@ -647,20 +596,15 @@ __global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(1))) v
 
 // Lane-per-nonzero engine (lane_eval.hpp): doubles, 25 or 50 slots per factor row; NW waves per row; one wave per SIMD, or
 // (SMALL: one register set, 14 KB of LDS per wave) two.
-// (lane_two: instances compiled for two waves per SIMD -- the SMALL ones, and CG on doubles with one VGPR set + one LDS set, whose
-// 31 KB of LDS per row let a CU take five rows, PMF_LANE_FIVE)
-template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF, int LP> constexpr bool lane_two()
+// (lane_two: instances compiled for two waves per SIMD -- the SMALL ones)
+template <bool SMALL> constexpr bool lane_two() { return SMALL; }
+template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, int LP = 0, int TX = 0>
+__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(lane_two<SMALL>() ? 2 : 1, lane_two<SMALL>() ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
 {
-    return SMALL || (LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP>::FIVE && METHOD == K_CG);
-}
-template <class T, int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL, bool PF = false, int LP = 0, int TX = 0>
-__global__ __launch_bounds__(WAVE* NW) __attribute__((amdgpu_waves_per_eu(lane_two<T, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 2 : 1, lane_two<T, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 2 : 1))) void half_sweep_lane_kernel(const HalfArgs<T> a)
-{
-    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, PF, LP, TX>;
+    using EV = LaneEval<T, KS, LV, LA, LL, NW, SMALL, LP, TX>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EV::SMEM_BYTES];
     EV ev;
-    if constexpr (PF) sweep_rows_pf<EV, T, EV::NC, METHOD>(a, ev, smem);
-    else sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
+    sweep_rows<EV, T, EV::NC, METHOD, NW>(a, ev, smem);
 }
 
 namespace {
@@ -793,13 +737,13 @@ template <int M, int S> int launch_team(hipStream_t stream, int method, const Ha
 }
 
 // lane-per-nonzero launches
-template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false, bool PF = false, int LP = 0, int TX = 0> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
+template <int METHOD, int KS, int LV, int LA, int LL, int NW, bool SMALL = false, int LP = 0, int TX = 0> int launch_lane(hipStream_t stream, const HalfArgs<real_t>& a, unsigned grid_mult)
 {
     if constexpr (tu_has(METHOD)) {
-        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, PF, LP, TX>;
-        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP, TX>;
+        using EV = LaneEval<real_t, KS, LV, LA, LL, NW, SMALL, LP, TX>;
+        auto kern = half_sweep_lane_kernel<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, LP, TX>;
         // workgroups per CU: one (SMALL: two) waves per SIMD, and the LDS each takes
-        const int occ = std::max(1, std::min((lane_two<real_t, METHOD, KS, LV, LA, LL, NW, SMALL, PF, LP>() ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
+        const int occ = std::max(1, std::min((lane_two<SMALL>() ? 8 : 4) / NW, (int)(LDS_PER_CU / (size_t)EV::SMEM_BYTES)));
         const unsigned grid = (unsigned)std::min<size_t>(a.nrows, (size_t)t_num_cu * (size_t)occ * grid_mult);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * NW), 0, stream, a);
         HIP_TRY(hipGetLastError());
@@ -826,44 +770,31 @@ template <int METHOD> int launch_lane_shape(hipStream_t stream, int s_load, int 
         else if (s_load == 25) {
             switch (key) {
                 case 10011: return launch_lane<METHOD, 25, 1, 0, 0, 1, true>(stream, a, grid_mult);
-                case 10021: return launch_lane<METHOD, 25, 1, 0, 0, 2, true>(stream, a, grid_mult);
-#ifndef PMF_LANE_PF
-#define PMF_LANE_PF 0   // rows of 65 .. 128 nonzeros: the next row's tile prefetched into AGPRs while this one is solved (lane_eval.hpp, PF_).
-                        // Built, parity-green, and NOT adopted: C3 A half 18.78 ms with it, 18.80 without -- with maxupd = 1 the half
-                        // already runs at the fabric's gather rate (8.8 ms for 40 GB), with maxupd = 5 the waves are waiting on LDS
-                        // round trips and dependent fp64 chains, not on the gather (PMC: SQ_WAIT_ANY 28 % with, 31 % without).  Its asm
-                        // loads into AGPRs are also only safe while the instance has no scratch (lane_eval.hpp, PMF_LANE_DIRECT_A).
-#endif
-                case 10110: return launch_lane<METHOD, 25, 1, 0, 1, 1, false, PMF_LANE_PF != 0>(stream, a, grid_mult);
+                case 10110: return launch_lane<METHOD, 25, 1, 0, 1, 1>(stream, a, grid_mult);
                 case 12110: return launch_lane<METHOD, 25, 1, 2, 1, 1>(stream, a, grid_mult);
                 case 12120: return launch_lane<METHOD, 25, 1, 2, 1, 2>(stream, a, grid_mult);
                 case 12140: return launch_lane<METHOD, 25, 1, 2, 1, 4>(stream, a, grid_mult);
-                case 112140: return launch_lane<METHOD, 25, 1, 2, 1, 4, false, false, 16>(stream, a, grid_mult);
+                case 112140: return launch_lane<METHOD, 25, 1, 2, 1, 4, false, 16>(stream, a, grid_mult);
                 case 110011:
                     if constexpr (METHOD != K_TNCG) {
-                        if (lp == 32) return launch_lane<METHOD, 25, 1, 0, 0, 1, true, false, 32>(stream, a, grid_mult);
-                        if (lp == 48) return launch_lane<METHOD, 25, 1, 0, 0, 1, true, false, 48>(stream, a, grid_mult);
+                        if (lp == 32) return launch_lane<METHOD, 25, 1, 0, 0, 1, true, 32>(stream, a, grid_mult);
                     }
                     break;
             }
         } else if (s_load == 50) {
-            if (tx == 48 && key == 10010) return launch_lane<METHOD, 50, 1, 0, 0, 1, false, false, 0, 48>(stream, a, grid_mult);
-            if (tx == 64 && key == 10010) return launch_lane<METHOD, 50, 1, 0, 0, 1, false, false, 0, 64>(stream, a, grid_mult);
+            if (tx == 48 && key == 10010) return launch_lane<METHOD, 50, 1, 0, 0, 1, false, 0, 48>(stream, a, grid_mult);
+            if (tx == 64 && key == 10010) return launch_lane<METHOD, 50, 1, 0, 0, 1, false, 0, 64>(stream, a, grid_mult);
             switch (key) {
-                case 10010: return launch_lane<METHOD, 50, 1, 0, 0, 1>(stream, a, grid_mult);
-                case 10110: return launch_lane<METHOD, 50, 1, 0, 1, 1>(stream, a, grid_mult);
                 case 10020: return launch_lane<METHOD, 50, 1, 0, 0, 2>(stream, a, grid_mult);
-                case 110040: if (lp == 32) return launch_lane<METHOD, 50, 1, 0, 0, 4, false, false, 32>(stream, a, grid_mult); break;
+                case 110040: if (lp == 32) return launch_lane<METHOD, 50, 1, 0, 0, 4, false, 32>(stream, a, grid_mult); break;
             }
         }
     } else {
         if (s_load == 13) {
             if constexpr (METHOD == K_PG) {
                 switch (key) {
-                    case 20081: return launch_lane<METHOD, 13, 2, 0, 0, 8, true>(stream, a, grid_mult);
-                    case 30081: return launch_lane<METHOD, 13, 3, 0, 0, 8, true>(stream, a, grid_mult);
                     case 40041: return launch_lane<METHOD, 13, 4, 0, 0, 4, true>(stream, a, grid_mult);
-                    case 140041: if (lp == 16) return launch_lane<METHOD, 13, 4, 0, 0, 4, true, false, 16>(stream, a, grid_mult); break;
+                    case 140041: if (lp == 16) return launch_lane<METHOD, 13, 4, 0, 0, 4, true, 16>(stream, a, grid_mult); break;
                 }
             } else {
                 switch (key) {
@@ -950,7 +881,7 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
 #else
     if (o.team > 1 && o.team != GT_M) {
         if (o.team == 2 && o.reg_S == 32) return launch_team<2, 32>(o.main_stream, method, a);
-        if constexpr (PMF_TEAM_S36) { if (o.team == 2 && o.reg_S == 36) return launch_team<2, 36>(o.main_stream, method, a); }
+        if (o.team == 2 && o.reg_S == 36) return launch_team<2, 36>(o.main_stream, method, a);
         if (o.team == 3 && o.reg_S == 28) return launch_team<3, 28>(o.main_stream, method, a);
         if (o.team == 3 && o.reg_S == 32) return launch_team<3, 32>(o.main_stream, method, a);
         if (o.team == 4 && o.reg_S == 32) return launch_team<4, 32>(o.main_stream, method, a);
@@ -976,11 +907,9 @@ int launch_one_here(int method, const OneLaunch& o, const HalfArgs<real_t>& a)
         return 1;
     }
     if (o.nw > 1) {
-#ifndef PMF_LONG_SPECIAL
-#define PMF_LONG_SPECIAL 1   // the long-row path with the compile-time slot counts of the BASELINE configs too (and with them the prefetch of the next chunk)
-#endif
-        if (PMF_LONG_SPECIAL && !o.generic_only && o.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A, LONG_NW>(o.long_stream, method, a, o.lds, o.grid);
-        else if (PMF_LONG_SPECIAL && !o.generic_only && o.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B, LONG_NW>(o.long_stream, method, a, o.lds, o.grid);
+        // (the long-row path takes the compile-time slot counts of the BASELINE configs too, and with them the prefetch of the next chunk)
+        if (!o.generic_only && o.s_load == SPECIAL_SL_A) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_A, LONG_NW>(o.long_stream, method, a, o.lds, o.grid);
+        else if (!o.generic_only && o.s_load == SPECIAL_SL_B) rc = launch_method<SLOT_ELEMS, SPECIAL_SL_B, LONG_NW>(o.long_stream, method, a, o.lds, o.grid);
         else switch (o.spl) {
             case 1: rc = launch_method<1 * SLOT_ELEMS, 0, LONG_NW>(o.long_stream, method, a, o.lds, o.grid); break;
             case 2: rc = launch_method<2 * SLOT_ELEMS, 0, LONG_NW>(o.long_stream, method, a, o.lds, o.grid); break;

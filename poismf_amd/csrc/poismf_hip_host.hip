@@ -503,11 +503,7 @@ int build_half(Half& h, hipStream_t stream, const real_t* val, const sparse_ix* 
     return bad;
 }
 
-bool prefetch_enabled()
-{
-    static const bool off = getenv("POISMF_HIP_NO_PREFETCH") != nullptr;  // testing knob
-    return !off;
-}
+bool prefetch_enabled() { return true; }   // (streamed rows request the next chunk's tile a chunk ahead: row_eval.hpp, PF)
 
 TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_pq)
 {
@@ -536,7 +532,6 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_p
     // (C3 B half, CG fp64: 32 nonzeros without prefetch 103.9 ms, with 96.6; 48 with prefetch 82.6; 64 without 111.7)
     if (!single_pass && prefetch_enabled() && ((size_t)g.s_load == (size_t)SPECIAL_SL_A || (size_t)g.s_load == (size_t)SPECIAL_SL_B))
         stream_chunk = std::max(stream_chunk, std::max(16u, (unsigned)(PMF_PRE * WAVE / g.s_load) / 16 * 16));
-    if (const char* e = getenv("POISMF_HIP_STREAM_CHUNK")) stream_chunk = (unsigned)std::max(16, atoi(e));  // tuning knob
     unsigned cap = want;
     g.resident = 1;
     TileGeom probe = g;
@@ -550,14 +545,12 @@ TileGeom plan_geom(size_t k, unsigned bin_max_nnz, bool single_pass, bool want_p
     g.cap = (int)cap;
     // CG: cache T.x and T.d per nonzero when both fit next to the tile (up to 48 KiB for the pair); longer rows
     // fall back to the direct line search
-    static const bool no_cache = getenv("POISMF_HIP_CG_NOCACHE") != nullptr;  // testing knob
     // Only for streamed rows: there every line-search trial would otherwise be a fresh gather from L2/HBM
     // (C3 B half: 247 -> 146 ms).  For LDS-resident rows a trial is a cheap pass over the tile already and the
     // cached variant buys nothing: it halves the passes over the tile (C2 CG fp64: 20 -> 10 per row) and the sweep takes
     // the same 10.3 ms -- those rows are bound by the solver's chain of k-vector reductions and scalar decisions at one
-    // wave per SIMD, not by the tile passes (POISMF_HIP_CG_CACHE_RESIDENT=1 switches it on for them).
-    static const bool cache_resident = getenv("POISMF_HIP_CG_CACHE_RESIDENT") != nullptr;  // tuning knob
-    if (want_pq && !no_cache && (!g.resident || cache_resident) && (size_t)2 * bin_max_nnz * sizeof(real_t) <= 48 * 1024)
+    // wave per SIMD, not by the tile passes.
+    if (want_pq && !g.resident && (size_t)2 * bin_max_nnz * sizeof(real_t) <= 48 * 1024)
         g.pq_cap = (int)((bin_max_nnz + 15u) / 16u * 16u);
     g.prefetch = (!g.resident && prefetch_enabled()) ? 1 : 0;
     return g;
@@ -632,8 +625,7 @@ static std::mutex g_stream_mutex;
 static std::vector<hipStream_t> g_idle_streams[64];
 static int cached_stream(int device, hipStream_t* out)
 {
-    static const bool no_cache = getenv("POISMF_HIP_NO_STREAM_CACHE") != nullptr;   // testing knob
-    if (!no_cache && device >= 0 && device < 64) {
+    if (device >= 0 && device < 64) {
         std::lock_guard<std::mutex> lk(g_stream_mutex);
         auto& v = g_idle_streams[device];
         if (!v.empty()) { *out = v.back(); v.pop_back(); return 0; }
@@ -1140,9 +1132,9 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     static const bool no_lane = getenv("POISMF_HIP_NO_LANE") != nullptr;  // testing knob
     const bool lane_ok = !no_lane && !single_pass && dimF < ((size_t)1 << 24) && ldF * sizeof(real_t) < ((size_t)1 << 24) &&
                          (dimF + 1) * ldF * sizeof(real_t) + 16 < ((size_t)1 << 32);
-    static const bool no_long = getenv("POISMF_HIP_NO_LONGROW") != nullptr;  // testing knob
     unsigned long_thr = LONG_ROW_NNZ;
-    if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob
+    if (const char* e = getenv("POISMF_HIP_LONGROW_NNZ")) long_thr = (unsigned)std::max(64, atoi(e));  // testing knob (a huge value: no eight-wave rows at all)
+    const bool no_long = long_thr >= 0x40000000u;
     std::vector<Bin> bins;   // of the segments this call runs, in order
     for (size_t j = 0; j < h.segs.size(); j++)
         if (seg < 0 || (size_t)seg == j) bins.insert(bins.end(), h.segs[j].bins.begin(), h.segs[j].bins.end());
@@ -1153,9 +1145,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             LaneShape ls = lane_shape_for(b.cls, g.s_load, pm);
             // k = 100 fp64 rows above 64 nonzeros on the B half: rounds 3-4 left them to the streamed launch (with only the 65 .. 128-nonzero rows
             // taken out, that launch lost the short-row tail that kept its wave slots busy: B half 234.6 -> 296.0 ms); since round 5 every row up
-            // to 384 nonzeros has a resident instance and the streamed launch keeps the 3 k rows above.  POISMF_HIP_K100_LANE_B=0: as in round 4
-            static const bool k100_lane_b = getenv("POISMF_HIP_K100_LANE_B") == nullptr || atoi(getenv("POISMF_HIP_K100_LANE_B")) != 0;
-            if (sizeof(real_t) == 8 && g.s_load == 50 && b.cls > 64 && which == 0 && !k100_lane_b) ls.waves = 0;
+            // to 384 nonzeros has a resident instance and the streamed launch keeps the 3 k rows above.
             // k = 100 fp64 under TNCG, rows of 385 .. 8192 nonzeros (round 5): a TEAM of ceil(class / 384) four-wave workgroups keeps the row
             // RESIDENT (each member its 1/M of the nonzeros in one register set + a partial LDS set per wave, lane_eval.hpp TM_) and the members
             // exchange their sums per evaluation -- instead of re-streaming 800 bytes per nonzero for each of ~70 evaluations (84 % of config C5's
@@ -1259,29 +1249,18 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     }
     static const bool static_rows = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;  // testing knob
     const bool dynamic = !is_pg && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
-    // PG's multi-wave lane launches: 0 = one row per workgroup (the default, below), 1 = persistent workgroups pulling rows from the queue,
-    // 2 = persistent workgroups, rows dealt out statically (rounds 2-4a)      (tuning knob)
-    static const int pg_lane_rows = getenv("POISMF_HIP_PG_LANE_ROWS") ? atoi(getenv("POISMF_HIP_PG_LANE_ROWS")) : 0;
-    const bool pg_queue = is_pg && pg_lane_rows == 1 && !static_rows && launches.size() <= (size_t)MAX_LAUNCHES;
-    if (dynamic || pg_queue) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
+    // (PG's multi-wave lane launches take ONE ROW PER WORKGROUP, below; persistent workgroups on the queue or with static shares -- rounds 2-4a,
+    // POISMF_HIP_PG_LANE_ROWS -- lost to it, DESIGN.md 6.0, and went in round 6)
+    if (dynamic) HIP_TRY(hipMemsetAsync(s->d_queue, 0, sizeof(unsigned) * MAX_LAUNCHES, s->stream));
     // the few workgroup-per-row launches of the power-law tail occupy a few dozen CUs for a long time: run them on a
     // second stream beside the other bins (fork after the column sums, join before anything reads the result)
-    // Several launches per half: they also alternate between the two streams (each to the one with less work queued so
-    // far), so that the tail of one bin overlaps the start of the next.
-    // (off by default: overlapping launches make the per-kernel durations of a profile overlap too)
     static const bool no_fork = getenv("POISMF_HIP_NO_FORK") != nullptr;  // testing knob
-    static const bool fork_bins = getenv("POISMF_HIP_FORK_BINS") != nullptr;  // tuning knob
     bool any_long = false;
     for (const Launch& L : launches) any_long = any_long || (L.nw > 1 && L.reg_S == 0 && L.lane_L == 0);
-    const bool forked = !no_fork && launches.size() > 1 && (any_long || fork_bins);
-    // (two TEAM launches must never run beside each other: each waits for partners that need the CUs the other's partial teams hold -- with lane
-    // teams in the half, the giant rows' launch stays on the main stream, in front of them)
-    bool any_lane_team = false;
-    for (const Launch& L : launches) any_lane_team = any_lane_team || (L.team > 1 && L.lane_L > 0);
-    // POISMF_HIP_LANE_TEAM_STREAM=1 (tuning knob): giant rows and lane teams one after the other on the SECOND stream, beside the main stream's non-team bins
-    static const int lt_stream = getenv("POISMF_HIP_LANE_TEAM_STREAM") ? atoi(getenv("POISMF_HIP_LANE_TEAM_STREAM")) : 1;
-    const bool teams_on_main = any_lane_team && lt_stream == 0;
-    hipStream_t long_stream = (forked && !teams_on_main) ? s->aux_stream : s->stream;
+    const bool forked = !no_fork && launches.size() > 1 && any_long;
+    // (two TEAM launches must never run beside each other: each waits for partners that need the CUs the other's partial teams hold -- giant rows
+    // and lane teams follow one another on the SECOND stream, beside the main stream's non-team bins)
+    hipStream_t long_stream = forked ? s->aux_stream : s->stream;
     double queued[2] = { 0.0, 0.0 };
     // The long rows go to the second stream to run NEXT TO the other bins, not after them.  The other bins' kernels are persistent
     // (a workgroup keeps its CU until the bin's queue is empty): whichever kernel reaches the chip first fills it, and on config C5
@@ -1289,8 +1268,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     // takes 150 alone).  So every workgroup of the long-row launch counts itself in when it starts, and the main stream waits for
     // that count (a one-wave gate kernel with a time limit, above; rounds 3-4a: hipStreamWaitValue32) before it launches anything else.
     // Arrivals only ever grow, so a chip that cannot hold the whole launch at once delays the main stream by the gate's 2 ms, no more.
-    static const bool no_arrive = getenv("POISMF_HIP_NO_ARRIVE_WAIT") != nullptr;   // testing knob
-    const bool hold_back = forked && any_long && !no_arrive && !teams_on_main;
+    const bool hold_back = forked && any_long;
     if (hold_back) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, sizeof(unsigned), s->stream));
     // ---- everything the team launches of this call need, once, on the main stream, before anything of the half is on the chip: a zeroed
     // buffer area, row-queue head (+ one for the re-run), error word and tally per launch, and a copy of the rows they start from
@@ -1364,7 +1342,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             const char* m = is_pg ? "pg" : p->method == POISMF_EVAL ? "eval" : pm == POISMF_CG ? "cg" : "tncg";
             const char* t = sizeof(real_t) == 4 ? "float" : "double";
             if (L.lane_L > 0 && L.team > 1) snprintf(txt, sizeof txt, "half_sweep_lane_team_kernel<%s,%s,KS=%d,V=%d,L=0+%d,NW=%d,M=%d> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_LP, L.nw, L.team, L.count);
-            else if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP == 48 ? "+48" : L.lane_LP == 32 ? "+32" : L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.lane_tx == 48 ? ",TX=48" : L.lane_tx == 64 ? ",TX=64" : "", L.count);
+            else if (L.lane_L > 0) snprintf(txt, sizeof txt, "half_sweep_lane_kernel<%s,%s,KS=%d,V=%d,A=%d,L=%d%s,NW=%d%s%s> rows=%u;", t, m, L.geom.s_load, L.lane_L, L.lane_A, L.lane_LL, L.lane_LP == 32 ? "+32" : L.lane_LP ? "+16" : "", L.nw, L.lane_small ? ",2/SIMD" : "", L.lane_tx == 48 ? ",TX=48" : L.lane_tx == 64 ? ",TX=64" : "", L.count);
             else if (L.team == GT_M && L.reg_S == 0) snprintf(txt, sizeof txt, "half_sweep_giant_kernel<%s,%s,NW=%d,M=%d,streamed cap=%d> rows=%u;", t, m, L.nw, L.team, L.geom.cap, L.count);
             else if (L.team > 1) snprintf(txt, sizeof txt, "half_sweep_team_kernel<%s,%s,S=%d,NW=%d,M=%d> rows=%u;", t, m, L.reg_S, L.nw, L.team, L.count);
             else if (L.reg_S > 0 && L.nw == 1) snprintf(txt, sizeof txt, "half_sweep_reg_kernel<%s,%s,S=%d> rows=%u;", t, m, L.reg_S, L.count);
@@ -1374,7 +1352,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
             snprintf(lname, sizeof lname, "%s", txt);
             if (char* sp = strstr(lname, " rows=")) *sp = 0;
         }
-        a.queue = (dynamic || (pg_queue && L.lane_L > 0 && L.nw > 1)) ? s->d_queue + launch_no : nullptr;
+        a.queue = dynamic ? s->d_queue + launch_no : nullptr;
         a.stop = is_pg ? nullptr : (const unsigned*)g_stop_word;   // (pinned host memory, portable: the same address on every device)
         launch_no++;
         a.perm_begin = L.begin;
@@ -1398,7 +1376,7 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         const bool lane_team = L.team > 1 && L.lane_L > 0;
         a.team_members = (unsigned)std::max(1, L.team);
         // (a giant-row team launch lives on the stream the long rows run on)
-        hipStream_t tst = (giant || (lane_team && !teams_on_main)) ? long_stream : s->stream;
+        hipStream_t tst = (giant || lane_team) ? long_stream : s->stream;
         const size_t my_slot = team_no;
         if (L.team > 1) {
             // one dispatch: its queue head, buffer area, error word and tally are its own and were zeroed before the half began
@@ -1423,29 +1401,24 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         // neither the cross-row pipeline nor start delays account for it; the workgroup-wide ticket's two barriers per row remain).
         // (Not for CG / TNCG, whose rows differ in cost and want the longest-first queue: CG fp32 B half 11.25 -> 13.17 ms; not for the
         // eight-wave register kernel, one workgroup per CU: 1.83 -> 1.90.)
-        if (is_pg && L.lane_L > 0 && L.nw > 1 && pg_lane_rows == 0) grid_mult = 1u << 20;
-        if (const char* e = getenv("POISMF_HIP_GRID_MULT")) grid_mult = (unsigned)std::max(1, atoi(e));  // tuning knob
+        if (is_pg && L.lane_L > 0 && L.nw > 1) grid_mult = 1u << 20;
         unsigned grid = (unsigned)std::min<size_t>(L.count, (size_t)s->num_cu * waves_per_cu * grid_mult);
         if (giant) {
-            // whole teams only: as many as the chip holds at one workgroup per CU (POISMF_HIP_GIANT_TEAMS: fewer, leaving CUs to the other bins)
-            static const unsigned want = getenv("POISMF_HIP_GIANT_TEAMS") ? (unsigned)std::max(1, atoi(getenv("POISMF_HIP_GIANT_TEAMS"))) : GT_TEAMS_MAX;
-            const unsigned teams = std::max(1u, std::min(std::min((unsigned)L.count, want), std::min((unsigned)GT_TEAMS_MAX, (unsigned)s->num_cu / (unsigned)GT_M)));
+            // whole teams only: as many as the chip holds at one workgroup per CU
+            const unsigned teams = std::max(1u, std::min((unsigned)L.count, std::min((unsigned)GT_TEAMS_MAX, (unsigned)s->num_cu / (unsigned)GT_M)));
             grid = teams * (unsigned)GT_M;
         }
         if (lane_team) grid = std::max(1u, std::min((unsigned)L.count, (unsigned)s->num_cu / (unsigned)L.team)) * (unsigned)L.team;   // whole teams, one workgroup per CU
         int rc = 1;
         // (with long rows on the second stream, the one-wave bins that follow go wherever less work is queued: on C5 the lane rows
         // run behind the giant rows on the second stream while the mid-length bin has the main one)
-        int lane_stream = (forked && (fork_bins || any_long) && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
-        static const int force_lane_stream = getenv("POISMF_HIP_LANE_STREAM") ? atoi(getenv("POISMF_HIP_LANE_STREAM")) : -1;   // tuning knob: 0 / 1 = every one-wave lane bin on the main / second stream
-        if (force_lane_stream >= 0 && forked && L.nw == 1 && L.lane_L > 0) lane_stream = force_lane_stream ? 1 : 0;
+        const int lane_stream = (forked && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
         hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {
             OneLaunch o;
             o.reg_S = L.reg_S; o.nw = L.nw; o.team = L.team; o.lane_L = L.lane_L; o.lane_A = L.lane_A; o.lane_LL = L.lane_LL; o.lane_small = L.lane_small; o.lane_LP = L.lane_LP; o.lane_tx = L.lane_tx; o.s_load = a.geom.s_load; o.spl = slots_per_lane(s->k);
-            static const bool generic_only = getenv("POISMF_HIP_GENERIC") != nullptr;  // testing knob: skip the specialisations
-            o.generic_only = generic_only;
+            o.generic_only = false;   // (the generic slot-count kernels are what every k other than the BASELINE configs' takes: tests/test_gpu_regtile.py)
             o.main_stream = lane_team ? tst : s->stream; o.bin_stream = bin_stream; o.long_stream = long_stream;
             o.lds = lds; o.grid = grid; o.grid_mult = grid_mult;
             o.device = s->device; o.num_cu = s->num_cu;

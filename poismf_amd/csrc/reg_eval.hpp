@@ -37,9 +37,6 @@ template <int I, int N, class Fn> __device__ __forceinline__ void static_for(Fn&
     }
 }
 
-#ifndef PMF_BCAST64_DPP
-#define PMF_BCAST64_DPP 1
-#endif
 // value of lane U of the caller's group of G lanes (ds_swizzle, bit-mask mode inside each half-wave:
 // src = (lane & ~(G - 1)) | U)
 template <int G, int U> __device__ __forceinline__ int group_bcast_i32(int v)
@@ -55,7 +52,7 @@ template <int G, int U> __device__ __forceinline__ double group_bcast(double v)
 {
     // sixteen lanes are one DPP row: v_mov_b64_dpp row_newbcast (the one DPP control 64-bit operands take) instead of two trips
     // through the LDS crossbar -- the fp64 kernels run one wave per SIMD and wait every such trip out
-    if constexpr (G == 16 && PMF_BCAST64_DPP) return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + U, 0xf, 0xf, true);
+    if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + U, 0xf, 0xf, true);
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = (unsigned)group_bcast_i32<G, U>((int)(unsigned)b);
     const unsigned hi = (unsigned)group_bcast_i32<G, U>((int)(unsigned)(b >> 32));
@@ -176,10 +173,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     static constexpr int RED_BYTES = NW_ * KP * (int)sizeof(T) + (M_ > 1 ? NW_ * 8 * TEAM_SC : 16 * ((NW_ * 8 + 15) / 16));
     static constexpr int TEAM_BYTES = M_ > 1 ? KP * (int)sizeof(T) + 8 * TEAM_SC : 0;           // team totals: a k-vector and the scalars
     // PARKS: six k-vectors per wave wait in LDS during the passes of cg_row_cached (solvers.hpp)
-#ifndef PMF_PARK
-#define PMF_PARK 1
-#endif
-    static constexpr bool PARKS = PMF_PARK && sizeof(T) == 8 && M_ > 1;
+    static constexpr bool PARKS = sizeof(T) == 8 && M_ > 1;
     static constexpr int PARK_SLOTS = 6;
     static constexpr int PARK_BYTES = PARKS ? NW_ * PARK_SLOTS * KP * (int)sizeof(T) : 0;
     static constexpr int PARK_OFFSET = (NW_ > 1 ? 2 * RED_BYTES + 16 : 0) + TEAM_BYTES;
@@ -226,14 +220,11 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     // lane finishes stay in registers (pv / qv, one per batch); pbuf / qbuf are only tags that tell eval() which of the
     // two a pass is to keep.  First used by the fp64 single-wave kernels (pq_cap > 0): one wave per SIMD, where an Armijo trial
     // as two logs instead of a pass over the tile is what shortens the row (C3 CG fp64 A half: 37.3 -> see DESIGN.md); the
-    // teams and, since the cache became a compile-time property of an instance, the fp32 kernels take it too (PMF_CACHE32).
+    // teams and, since the cache became a compile-time property of an instance, the fp32 kernels take it too.
     int pq_cap;
     T* pbuf;
     T* qbuf;
-#ifndef PMF_CACHE32
-#define PMF_CACHE32 1
-#endif
-    static constexpr bool CACHED = (sizeof(T) == 8 && (NW_ == 1 || M_ > 1)) || (PMF_CACHE32 && sizeof(T) == 4);   // compile-time: no trace of the cache in the other instances
+    static constexpr bool CACHED = (sizeof(T) == 8 && (NW_ == 1 || M_ > 1)) || sizeof(T) == 4;   // compile-time: no trace of the cache in the other instances
     static constexpr bool MAY_CACHE = CACHED;
     static constexpr bool CACHED_GRAD = CACHED;   // cg_row_cached may take gradients from the cached predictions
     T pv[CACHED ? NB : 1], qv[CACHED ? NB : 1];
@@ -616,8 +607,7 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
     __device__ __forceinline__ T lane_dot(const SA (&w)[NS]) const
     {
         if constexpr (SN == 4) {
-#ifndef PMF_DOT_PLAIN
-            // pk_mul + pk_fma + add per step.  (-DPMF_DOT_PLAIN: mul + 3 fma -- fewer SIMD cycles on paper, a packed op takes two
+            // pk_mul + pk_fma + add per step.  (a plain mul + 3 fma -- fewer SIMD cycles on paper, a packed op takes two
             // passes on CDNA4's SIMD-32, but one more instruction to issue: C4 PG(10) 12.91 -> 13.18 ms, same box.)
             typedef T V2 __attribute__((ext_vector_type(2)));
             V2 p = (V2){ w[0].v[0], w[0].v[1] } * (V2){ a[0], a[1] };
@@ -628,18 +618,6 @@ template <class T, int S, int G_ = 16, int NS_ = 1, int NW_ = 1, int M_ = 1> str
                 p = __builtin_elementwise_fma((V2){ w[n].v[2], w[n].v[3] }, (V2){ a[4 * n + 2], a[4 * n + 3] }, p);
             }
             return p.x + p.y;
-#else
-            T p = w[0].v[0] * a[0];
-            p = fma_t(w[0].v[1], a[1], p);
-            p = fma_t(w[0].v[2], a[2], p);
-            p = fma_t(w[0].v[3], a[3], p);
-#pragma unroll
-            for (int n = 1; n < NS; n++) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) p = fma_t(w[n].v[e], a[4 * n + e], p);
-            }
-            return p;
-#endif
         } else {
             T p = fma_t(w[0].v[1], a[1], w[0].v[0] * a[0]);
 #pragma unroll

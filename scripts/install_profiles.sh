@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage: scripts/install_profiles.sh <tag> [round dir, default r05]: copy what scripts/profile_round.sh left in
+# usage: scripts/install_profiles.sh <tag> [round dir, default r06]: copy what scripts/profile_round.sh left in
 # gpurun_out/<tag>/ into profiles/<round>/ (tracked) and refresh profiles/hbm_traffic.json.  Only the files this script writes are
 # replaced: whatever else lives in the round's directory (probe outputs, run_config records, kernel_resource_usage.txt) stays.
 set -e
 cd "$(dirname "$0")/.."
-SRC=gpurun_out/$1; DST=profiles/${2:-r05}
+SRC=gpurun_out/$1; DST=profiles/${2:-r06}
 mkdir -p $DST/pmc
 cp $SRC/bench_line.json $DST/bench_line.json
 [ -f $SRC/bench_full.json ] && cp $SRC/bench_full.json $DST/bench_full.json
@@ -15,6 +15,7 @@ for n in pg10 pg1 cg64 cg32 tncg32 c5; do
   [ -f $SRC/kt_${n}_run_config.json ] && cp $SRC/kt_${n}_run_config.json $DST/
   for c in f w t sq; do f=$(find $SRC/pmc_${c}_$n -name summary.txt 2>/dev/null | head -1); [ -n "$f" ] && cp $f $DST/pmc/pmc_${c}_${n}.summary.txt; done
 done
+[ -f $SRC/kt_c5_timeline.txt ] && cp $SRC/kt_c5_timeline.txt $DST/kt_c5_timeline.txt
 cp $SRC/hbm_traffic.json profiles/hbm_traffic.json
 python3 - <<PY
 import csv, json, os

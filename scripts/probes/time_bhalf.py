@@ -1,6 +1,5 @@
 """Development: per-launch times of the B half (PG fp32, finite hyper-parameters) of the 1e8-nnz matrix for a few maxupd values.
-For variant builds that compile the lane kernels alone (-DPMF_LANE_ONLY; run with POISMF_HIP_PG_LONG_LANE=1 so that every item row
-takes a lane kernel).  usage: time_bhalf.py [maxupd ...]"""
+For variant builds that compile the lane kernels alone (-DPMF_LANE_ONLY: only the rows the lane engine takes are launched at all).  usage: time_bhalf.py [maxupd ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

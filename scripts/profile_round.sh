@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, through gpurun):  scripts/profile_round.sh <tag> [round name stamped into hbm_traffic.json, default r05]
+# usage (on the GPU box, through gpurun):  scripts/profile_round.sh <tag> [round name stamped into hbm_traffic.json, default r06]
 # Produces gpurun_out/<tag>/: the default bench line, rocprofv3 --kernel-trace --stats of the workloads behind it (PG fp32
 # with maxupd 10 and 1, CG fp64, CG fp32, TNCG fp32, all on the 1M x 100K / 1e8-nnz matrix) and PMC passes (FETCH_SIZE and WRITE_SIZE separately,
 # TCC hit / miss, SQ issue / wait counters) of the same commands.  scripts/install_profiles.sh copies the summaries to profiles/.
@@ -32,7 +32,7 @@ summaries() {
   find $OUT -name "*counter_collection.csv" -delete
   find $OUT -name "*kernel_trace.csv" -delete
   find $OUT -name "*agent_info.csv" -delete
-  python3 $R/scripts/traffic_from_pmc.py $OUT ${2:-r05} > $OUT/hbm_traffic.json
+  python3 $R/scripts/traffic_from_pmc.py $OUT ${2:-r06} > $OUT/hbm_traffic.json
 }
 summaries "$@"
 # config C5 (its own matrix, k = 100, tncg fp64) through scripts/run_config.py: 2 warm-up + 3 timed sweeps, no oracle sample.  Last, and
@@ -42,6 +42,9 @@ summaries "$@"
 C5="python3 $R/scripts/run_config.py C5 --warmup 2 --sweeps 3 --sample 0"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt_c5 -o kt --output-format csv -- $C5 > $OUT/kt_c5.log 2>&1
 grep '^{"config"' $OUT/kt_c5.log | tail -1 > $OUT/kt_c5_run_config.json
+# the TIMELINE of that run's last sweep (round 6): every half_sweep_* / team_* / hold_back dispatch with its start, end and queue -- which launch
+# ran beside which on the two streams of the B half (the --stats table cannot say)
+python3 $R/scripts/trace_timeline.py $OUT/kt_c5 60 > $OUT/kt_c5_timeline.txt 2>&1
 timeout 420 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f_c5 -o pmc --output-format csv -- $C5 > $OUT/pmc_f_c5.log 2>&1 || echo "pmc_f_c5: rc $?" >> $OUT/c5_pmc_status.txt
 timeout 420 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w_c5 -o pmc --output-format csv -- $C5 > $OUT/pmc_w_c5.log 2>&1 || echo "pmc_w_c5: rc $?" >> $OUT/c5_pmc_status.txt
 timeout 420 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_WAVES -d $OUT/pmc_sq_c5 -o pmc --output-format csv -- $C5 > $OUT/pmc_sq_c5.log 2>&1 || echo "pmc_sq_c5: rc $?" >> $OUT/c5_pmc_status.txt

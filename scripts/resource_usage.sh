@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: scripts/resource_usage.sh [out file, default profiles/r05/kernel_resource_usage.txt]
+# usage: scripts/resource_usage.sh [out file, default profiles/r06/kernel_resource_usage.txt]
 # Every row kernel's VGPRs / AGPRs / scratch / waves per SIMD / LDS as the compiler reports them (-Rpass-analysis=kernel-resource-usage),
 # one device-only compile of poismf_hip.hip per solver translation unit and precision, with the product build's flags.  ~6 minutes on 8 cores.
 cd "$(dirname "$0")/.."
-OUT=${1:-profiles/r05/kernel_resource_usage.txt}
+OUT=${1:-profiles/r06/kernel_resource_usage.txt}
 TMP=$(mktemp -d)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -Wno-unused-const-variable -Wno-pass-failed $POISMF_HIP_EXTRA_FLAGS"
 for prec in f64 f32; do

@@ -61,7 +61,7 @@ def run_child(tmp_path, tag, env, k=100, prec=False, repeat=1, maxupd=1500, w=1.
 LAST_UNCHANGED = None   # the UNCHANGED count the most recent child printed
 
 
-NO_TEAMS = any(os.environ.get(v) for v in ("POISMF_HIP_NO_TEAM", "POISMF_HIP_NO_GIANT_TEAMS", "POISMF_HIP_STATIC_ROWS", "POISMF_HIP_NO_LONGROW"))
+NO_TEAMS = any(os.environ.get(v) for v in ("POISMF_HIP_NO_TEAM", "POISMF_HIP_NO_GIANT_TEAMS", "POISMF_HIP_STATIC_ROWS")) or int(os.environ.get("POISMF_HIP_LONGROW_NNZ", "0")) > 100000
 
 
 @pytest.mark.parametrize("k,prec,w", [(100, False, 1.0), (100, False, 3.0), (50, False, 1.0), (20, False, 1.0)])

@@ -560,8 +560,8 @@ def test_coo_session_rejects_indices_outside_the_matrix():
 
 def test_sigint_ends_a_half_sweep_within_a_row():
     """ref: src/poismf.c:301, :360 -- the reference's CG / TNCG row loops test the interrupt flag before every row.  Rounds 1-4 looked at
-    it between half-sweeps only (config C5: up to 260 ms).  Since round 5 a host thread empties the device-side row queues when the
-    flag is set: every workgroup finishes the row it is on and leaves.  C5-shaped rows (user rows of ~48 nonzeros, item rows of ~100 with
+    it between half-sweeps only (config C5: up to 260 ms).  Since round 5 the SIGINT handler also sets a word in pinned host memory that the
+    row kernels read next to every row ticket (take_ticket, poismf_hip.hip): every workgroup finishes the row it is on and leaves.  C5-shaped rows (user rows of ~48 nonzeros, item rows of ~100 with
     mild skew, k = 100, tncg fp64): a half-sweep takes 100 ms and more, the call must be back within 50 ms of the signal."""
     import signal
     import threading

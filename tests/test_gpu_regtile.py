@@ -216,6 +216,38 @@ def test_weighted_rows_on_both_sides_of_every_hand_over(prec, method):
         compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
 
 
+@pytest.mark.parametrize("w", [1.0, 3.0])
+def test_pg_fp32_rows_of_1025_to_1088_nonzeros_on_the_partial_lds_set(w):
+    """Round 6: PG fp32, k = 50, rows of 1025 .. 1088 nonzeros take the lane engine's four-wave instance with four register sets and a PARTIAL
+    LDS set of 16 nonzeros per wave (lane_eval.hpp: LP_ under the scalar-operand dots and the transposing butterfly; two rows per CU) instead
+    of the register engine's eight-wave kernel.  Hyper-parameters that keep the factors alive (the Python defaults zero every entry within a
+    sweep, which would compare zeros with zeros); rows on either side of both hand-overs (1024 | 1025, 1088 | 1089), every share size of the
+    partial set (a wave's share of 257 .. 272 nonzeros leaves 1 .. 16 of them in LDS); against the oracle, three runs the same bits, and the
+    plan names the instance."""
+    k = 50
+    lengths = [1000, 1023, 1024, 1025, 1026, 1027, 1028, 1029, 1033, 1040, 1041, 1055, 1056, 1057, 1064, 1072, 1080, 1085, 1086, 1087, 1088, 1089, 1100, 1152]
+    csr, csc, A0, B0 = ragged_problem(lengths, 6000, k, True, seed=23)
+    kw = dict(l2_reg=1e3, step_size=1e-9, maxupd=10, w_mult=w)
+    A, B, args = gpu_run(csr, csc, A0, B0, "pg", 2, k, **kw)
+    Ar, Br = oracle_run(True, csr, csc, A0, B0, "pg", args)
+    assert np.isfinite(Ar).all() and Ar[:-1].min() > 0          # alive
+    assert not A[-1].any()
+    # fp32 sums over ~1000 nonzeros in two orders: ~sqrt(nnz) eps apart (measured 3e-6 .. 2e-5 on these rows; the suite's bound for long fp32 rows)
+    err = max(H.scaled_err(A, Ar), H.scaled_err(B, Br))
+    print(f"PG fp32 rows of 1000 .. 1152 nonzeros, w={w}: scaled error against the oracle {err:.3g}")
+    assert err <= 1e-4
+    for _ in range(2):
+        A2, B2, _ = gpu_run(csr, csc, A0, B0, "pg", 2, k, **kw)
+        assert np.array_equal(A, A2) and np.array_equal(B, B2)
+    s = api.Session(csr, csc, A0.shape[0], B0.shape[0], k, True)
+    s.set_factors(A0, B0)
+    s.half_sweep(1, s.make_params("pg", 1e3, w_mult=w, maxupd=10), 1e-9, 1.0)
+    plan = " ".join(name for name, _ in s.plan(1))
+    s.close()
+    if not any(os.environ.get(v) for v in ("POISMF_HIP_NO_LANE", "POISMF_HIP_NO_REGTILE")) and w == 1.0:
+        assert "half_sweep_lane_kernel<float,pg,KS=13,V=4,A=0,L=0+16,NW=4,2/SIMD>" in plan, plan
+
+
 K100_LENGTHS = [1, 16, 17, 40, 47, 48, 49, 60, 63, 64, 65, 100, 127, 128, 129, 130, 200, 255, 256, 257, 300, 320, 321, 383, 384, 385, 500, 700]
 
 
@@ -223,7 +255,7 @@ K100_LENGTHS = [1, 16, 17, 40, 47, 48, 49, 60, 63, 64, 65, 100, 127, 128, 129, 1
 def test_k100_fp64_lane_instances_on_both_sides_of_every_hand_over(method, w):
     """k = 100 fp64 (config C5's shape) -- the lane engine's instances of round 5 against the oracle, rows on either side of every
     hand-over: <= 48 / <= 64 nonzeros with the gradient accumulated from the row-major LDS image (lane_eval.hpp, TX_ = 48 / 64; the tile
-    lives in LDS only), 65 .. 128 two waves of one register set each (POISMF_HIP_K100_MID=1: one wave, one register + one LDS set), 129 .. 384 four waves of one register set + a partial LDS set of 32
+    lives in LDS only), 65 .. 128 two waves of one register set each, 129 .. 384 four waves of one register set + a partial LDS set of 32
     nonzeros (one row per CU), above that the streamed engine.  With weights the per-row constant term takes the column sums of the
     tile from the same image.  And the same rows three times give the same bits."""
     k = 100

@@ -39,8 +39,6 @@ def test_staged_copies_leave_no_trace(prec, method, kw, tmp_path):
         # round 4: run_poismf uploads the A side's matrix on the second stream while the first B half runs; here the whole matrix first
         "no_overlap": {"POISMF_HIP_NO_UPLOAD_OVERLAP": "1"},
         "no_overlap_staged": {"POISMF_HIP_NO_UPLOAD_OVERLAP": "1", "POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "3"},
-        # the staged copies alternate between two DMA queues (the session's stream and the pool's side stream); here all on the first
-        "one_queue": {"POISMF_HIP_ONE_DMA_QUEUE": "1", "POISMF_HIP_STAGED_MIN_BYTES": "1", "POISMF_HIP_HOST_THREADS": "7"},
     }
     res = {}
     for tag, env in runs.items():
@@ -51,7 +49,7 @@ def test_staged_copies_leave_no_trace(prec, method, kw, tmp_path):
                        timeout=600)
         res[tag] = np.load(out)
     assert np.isfinite(res["plain"]).all() and res["plain"].any()
-    for tag in ("staged3", "staged7", "staged1", "no_overlap", "no_overlap_staged", "one_queue"):
+    for tag in ("staged3", "staged7", "staged1", "no_overlap", "no_overlap_staged"):
         assert np.array_equal(res[tag], res["plain"]), tag
 
 
@@ -105,19 +103,18 @@ np.save({out!r}, np.concatenate([A.ravel(), B.ravel()]))
 
 
 def test_pg_row_hand_out_leaves_no_trace(tmp_path):
-    """PG's multi-wave lane launches hand their rows out one per workgroup (round 4); persistent workgroups on the queue or with static shares
-    (POISMF_HIP_PG_LANE_ROWS = 1 / 2) or another grid size must give the same bits: a row's arithmetic depends on its length
-    class alone."""
+    """PG's multi-wave lane launches hand their rows out one per workgroup (the hardware dispatcher decides who gets which, round 4; the
+    persistent-workgroup variants went in round 6): two fresh processes, and one that keeps every launch on one stream, give the same bits --
+    a row's arithmetic depends on its length class alone."""
     res = {}
-    for tag, env in {"fresh": {}, "queue": {"POISMF_HIP_PG_LANE_ROWS": "1"}, "static": {"POISMF_HIP_PG_LANE_ROWS": "2"},
-                     "static_g7": {"POISMF_HIP_PG_LANE_ROWS": "2", "POISMF_HIP_GRID_MULT": "7"}}.items():
+    for tag, env in {"fresh": {}, "again": {}, "one_stream": {"POISMF_HIP_NO_FORK": "1"}}.items():
         out = str(tmp_path / f"{tag}.npy")
         e = dict(os.environ)
         e.update(env)
         subprocess.run([sys.executable, "-c", CHILD_HANDOUT.format(root=ROOT, out=out)], check=True, env=e, cwd=ROOT, timeout=600)
         res[tag] = np.load(out)
     assert np.isfinite(res["fresh"]).all() and res["fresh"].any()
-    for tag in ("queue", "static", "static_g7"):
+    for tag in ("again", "one_stream"):
         assert np.array_equal(res[tag], res["fresh"]), tag
 
 
