@@ -227,6 +227,8 @@ inline LaneShape lane_shape_for(unsigned cls, int s_load, int method)
             // + a PARTIAL LDS set of 16 nonzeros per wave (4 KB; 76 KB of LDS per row: still two rows per CU) instead of the register engine's
             // eight-wave kernel at one row per CU (0.32 of the byte roofline, the worst bucket of round 5's headline: 1.83 -> 1.21 ms, 0.47)
             if (cls > 1024 && cls <= 1088) return { 4, 0, 0, 4, 1, 16 };
+            // (the A half's one-wave rows on this engine's one- and two-set instances, measured in round 6: the headline sweep 9.29 -> 10.75 ms -- the
+            // slot layout of reg_eval.hpp stays the cheaper one for single-wave PG rows; not kept)
             return { 0, 0, 0, 0, 0 };
         }
         if (cls <= 64) return { 1, 0, 0, 1, 1 };

@@ -1410,9 +1410,10 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         }
         if (lane_team) grid = std::max(1u, std::min((unsigned)L.count, (unsigned)s->num_cu / (unsigned)L.team)) * (unsigned)L.team;   // whole teams, one workgroup per CU
         int rc = 1;
-        // (with long rows on the second stream, the one-wave bins that follow go wherever less work is queued: on C5 the lane rows
-        // run behind the giant rows on the second stream while the mid-length bin has the main one)
-        const int lane_stream = (forked && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
+        // (with long rows on the second stream, the one-wave bins that follow go wherever less work is queued -- unless the half has TEAM launches:
+        // they follow one another on the second stream and are the half's critical path; round 6's timeline of a C5 sweep, profiles/r06/kt_c5_timeline.txt,
+        // showed the last one-wave bin queued behind all seven of them and running alone for 8 ms after the main stream had been idle for 33)
+        const int lane_stream = (forked && tslots.empty() && L.nw == 1 && queued[1] < queued[0]) ? 1 : 0;
         hipStream_t bin_stream = lane_stream ? s->aux_stream : s->stream;
         queued[L.nw > 1 ? 1 : lane_stream] += (double)L.count * (double)std::max(16, L.reg_S > 0 ? L.reg_S * REG_JG : L.geom.cap);
         {

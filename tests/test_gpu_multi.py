@@ -70,3 +70,48 @@ def test_eight_entry_device_list_on_power_law_rows(tmp_path, method, prec, k, kw
         res[tag] = np.load(out)
     assert np.isfinite(res["one"]).all()
     assert np.array_equal(res["one"], res["eight"])
+
+
+def test_declared_partials_are_used_for_their_own_factor_only():
+    """poismf_hip_session_partials_ready() is a one-shot promise about ONE factor's column sums (the last poismf_hip_session_colsum_partial's).
+    Round 5 kept a bare flag: a half-sweep over the OTHER factor, or one after that factor had been rewritten, took foreign / stale partial sums
+    for its own (advisor, round 5).  Now the promise names its factor: the half it belongs to consumes it (same bits as the full sum), any
+    other half computes its own first stage, and set_factors / factors_dirty withdraw it."""
+    from poismf_amd import api
+    from tests import helpers as H
+    csr, csc, A0, B0 = H.small_problem(5000, 3000, 200000, 50, False, seed=9)
+    s = api.Session(csr, csc, A0.shape[0], B0.shape[0], 50, False)
+    prm = s.make_params("cg", 1e4, maxupd=3)
+
+    def half(which, prepare=None):
+        s.set_factors(A0, B0)
+        if prepare is not None:
+            prepare()
+        s.half_sweep(which, prm, 1e-7, 1.0)
+        return s.get_factors()
+
+    ref = {w: half(w) for w in (0, 1)}
+
+    def declare(which):
+        def go():
+            s.colsum_partial(which, 0, s.colsum_blocks(which))   # every block, computed here: the honest case
+            s.partials_ready()
+        return go
+
+    for w in (0, 1):     # the promise kept: same bits as the sum the half computes itself
+        A, B = half(w, declare(w))
+        assert np.array_equal(A, ref[w][0]) and np.array_equal(B, ref[w][1]), w
+    for w in (0, 1):     # the promise made for the OTHER half's factor: declined, the half sums its own factor
+        A, B = half(w, declare(1 - w))
+        assert np.array_equal(A, ref[w][0]) and np.array_equal(B, ref[w][1]), w
+
+    def stale():         # partials of A declared, then A rewritten through set_factors: withdrawn
+        s.colsum_partial(0, 0, s.colsum_blocks(0))
+        s.partials_ready()
+        s.set_factors(A0 * 2.0, B0)
+    A, B = half(0, stale)
+    s.set_factors(A0 * 2.0, B0)
+    s.half_sweep(0, prm, 1e-7, 1.0)
+    A2, B2 = s.get_factors()
+    assert np.array_equal(B, B2)
+    s.close()
