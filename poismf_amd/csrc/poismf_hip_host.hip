@@ -255,6 +255,7 @@ struct poismf_hip_session {
     unsigned* d_team_eval_backup = nullptr; // profiling sessions: those rows' evaluation counters (a re-run must not count an abandoned launch's evaluations)
     size_t team_backup_elems = 0, team_eval_backup_rows = 0;
     bool team_launched = false;             // since the words were last read
+    bool teams_off = false;                 // a team launch of this session timed out: no more multi-CU launches for the rest of it (team_check)
     int colsum_waves = 512;           // blocks (of 8 waves) in the first stage of the column sums
     bool partials_given = false;      // d_partial already holds every block's partial sum for the NEXT half-sweep (poismf_hip_session_partials_ready)
     const real_t* partials_of = nullptr;   // ... of THIS factor (the last poismf_hip_session_colsum_partial's): a half-sweep over the other factor, a factor
@@ -913,8 +914,11 @@ static int team_check(poismf_hip_session* s)
     HIP_TRY(pmf_download(w, s->d_team_err, 2 * sizeof(unsigned), s->stream));
     s->team_launched = false;
     if (w[0] != 0) {
+        // (somebody else holds CUs: every further team launch would sit out its time-out as well -- 300 ms each, up to eight per half on config C5.
+        // The rest of this session plans without teams: the rows take the streamed kernels directly, which is what a re-run gives them anyway.)
+        s->teams_off = true;
         fprintf(stderr, "poismf_hip: %u multi-CU row launch(es) timed out waiting for a partner CU and were re-run on the streamed path "
-                        "(results are valid; another process or kernel is holding CUs)\n", w[0]);
+                        "(results are valid; another process or kernel is holding CUs; no further multi-CU launches in this session)\n", w[0]);
         HIP_TRY(hipMemsetAsync(s->d_team_err, 0, 2 * sizeof(unsigned), s->stream));
     }
     return 0;
@@ -1124,7 +1128,8 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
     const unsigned reg_max = reg_ns == 2 && REG_G == 16 ? (pm == POISMF_TNCG ? 112u : pm == POISMF_CG ? 144u : reg_nnz_max(pm))
                                                         : reg_nnz_max(pm);
     // teams: CG on doubles with two slots per lane (k = 50 fp64: 25 slots), rows handed out through the queue
-    static const bool no_team = getenv("POISMF_HIP_NO_TEAM") != nullptr;  // testing knob
+    static const bool no_team_env = getenv("POISMF_HIP_NO_TEAM") != nullptr;  // testing knob
+    const bool no_team = no_team_env || s->teams_off;
     static const bool static_rows_ = getenv("POISMF_HIP_STATIC_ROWS") != nullptr;
     const bool team_ok = !no_team && !static_rows_ && reg_ok && reg_ns == 2 && REG_G == 16 && sizeof(real_t) == 8 && pm == POISMF_CG;
     // lane-per-nonzero engine (lane_eval.hpp): doubles with 25 / 50 slots per factor row, CG and TNCG; 24-bit row ids and
@@ -1215,18 +1220,22 @@ static int half_sweep_impl(poismf_hip_session* s, int which, const poismf_hip_pa
         // So TNCG's streamed rows always take the eight-wave kernel (POISMF_HIP_LONGROW_NNZ overrides; CG caches its line search, PG
         // makes one gather per pass over the whole chip: they keep the one-wave streamed kernel below 8192 nonzeros).
         const unsigned long_thr_here = (pm == POISMF_TNCG && !g.resident && getenv("POISMF_HIP_LONGROW_NNZ") == nullptr) ? 0u : long_thr;
-        if (!no_long && b.cls > long_thr_here) {
-            // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
-            // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
-            g.resident = 0;
-            g.prefetch = prefetch_enabled() ? 1 : 0;
-            g.pq_cap = 0;
-            int cap = 128;
-            for (;;) {
-                g.cap = cap;
-                if (cap <= 16 || lds_bytes_per_block(g, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
-                cap -= 16;
-            }
+        // a workgroup of LONG_NW waves per row; every wave streams its own chunks: size the chunk so that
+        // LONG_NW private tiles and the reduction scratch fit in one CU's LDS
+        TileGeom gl = g;
+        gl.resident = 0;
+        gl.prefetch = prefetch_enabled() ? 1 : 0;
+        gl.pq_cap = 0;
+        for (int cap = 128;; cap -= 16) {
+            gl.cap = cap;
+            if (cap <= 16 || lds_bytes_per_block(gl, sizeof(real_t), LONG_NW) <= 150 * 1024) break;
+        }
+        // (round 6: eight private tiles of even 16 nonzeros do not fit a CU's LDS once a factor row is ~1.2 KB -- k > 146 in fp64, > 292 in fp32 --
+        // and the launch failed with "invalid argument", i.e. rc 1 for a TNCG fit at k = 200 fp64 with any row past the resident limit, found by
+        // scripts/knob_matrix.sh under POISMF_HIP_LONGROW_NNZ=256: such rows keep the one-wave streamed kernel below)
+        const bool long_fits = lds_bytes_per_block(gl, sizeof(real_t), LONG_NW) <= LDS_PER_CU;
+        if (!no_long && long_fits && b.cls > long_thr_here) {
+            g = gl;
             // TNCG re-streams such a row for every evaluation: a team of GT_M workgroups per row (row_eval.hpp, TM; POISMF_HIP_NO_GIANT_TEAMS=1:
             // one workgroup per row, rounds 1-4).  Decided by the solver alone: a row's arithmetic must not depend on its shard.
             static const bool no_giant = getenv("POISMF_HIP_NO_GIANT_TEAMS") != nullptr;
@@ -1719,6 +1728,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
         if (method == POISMF_PG) step_size *= 0.5;  // ref: :532-533
         HIP_TRY(hipStreamSynchronize(s->stream));
         if (it == 0) pmf_tl("first B half done");
+        if (team_check(s)) return 1;   // (a word of eight bytes, and only after a half that had team launches)
         if (g_should_stop) break;
 
         // ---- A half ----
@@ -1729,6 +1739,7 @@ int run_alternation(poismf_hip_session* s, const poismf_hip_params& p, size_t nu
         }
         HIP_TRY(hipStreamSynchronize(s->stream));
         if (it == 0) pmf_tl("first A half done");
+        if (team_check(s)) return 1;
         if (stopped_earlyA && stopped_earlyB) break;
     }
     return team_check(s);

@@ -248,6 +248,27 @@ def test_pg_fp32_rows_of_1025_to_1088_nonzeros_on_the_partial_lds_set(w):
         assert "half_sweep_lane_kernel<float,pg,KS=13,V=4,A=0,L=0+16,NW=4,2/SIMD>" in plan, plan
 
 
+@pytest.mark.parametrize("method,prec,k", [("tncg", False, 200), ("cg", False, 200), ("pg", False, 256), ("tncg", True, 400)])
+def test_streamed_rows_at_large_k_do_not_need_the_eight_wave_kernel(method, prec, k):
+    """Round 6, found by scripts/knob_matrix.sh: once a factor row is ~1.2 KB (k > 146 in fp64, > 292 in fp32) eight private LDS tiles of even 16
+    nonzeros do not fit a CU, and the eight-wave streamed launch -- which TNCG takes for EVERY row past the resident limit -- failed with "invalid
+    argument": run_poismf returned 1 for a TNCG fit at k = 200 fp64 as soon as a row had ~70 nonzeros.  Such rows now keep the one-wave streamed kernel.
+    Rows on both sides of the resident limit, against the oracle."""
+    lengths = [8, 30, 60, 90, 150, 400, 1500]
+    csr, csc, A0, B0 = ragged_problem(lengths, 4000, k, prec, seed=41)
+    kw = dict(maxupd=60) if method == "tncg" else (dict(l2_reg=1e3, step_size=1e-9) if method == "pg" else {})
+    A, B, args = gpu_run(csr, csc, A0, B0, method, 1, k, **kw)      # (rc 1 -> MemoryError before the fix)
+    Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
+    assert not A[-1].any()
+    if method == "tncg" and prec:
+        assert np.isfinite(A).all() and np.isfinite(B).all() and A.min() >= 0 and B.min() >= 0   # (fp32 TNCG: one-sided, as everywhere in this suite)
+        og = harness.poisson_objective(A, B, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
+        orf = harness.poisson_objective(Ar, Br, csr, args["l2_reg"], args["l1_reg"], args["w_mult"])
+        assert og <= orf + 1e-2 * abs(orf)
+    else:
+        compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
+
+
 K100_LENGTHS = [1, 16, 17, 40, 47, 48, 49, 60, 63, 64, 65, 100, 127, 128, 129, 130, 200, 255, 256, 257, 300, 320, 321, 383, 384, 385, 500, 700]
 
 
