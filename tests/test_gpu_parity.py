@@ -51,7 +51,8 @@ def oracle_run(is_float, csr, csc, A0, B0, method, args, nthreads=8):
     return A, B
 
 
-def compare(is_float, method, csr, args, A, B, Ar, Br, converged):
+def compare(is_float, method, csr, args, A, B, Ar, Br, converged, problem=None):
+    """problem = (csc, A0, B0): lets the TNCG fp64 bound be tied to the reference's own spread on this very problem (tests/helpers.py, tncg_yardstick)"""
     if not (np.isfinite(Ar).all() and np.isfinite(Br).all()):
         # PG has no guard against overflow (ref: poismf/__init__.py:37-41); when the reference blows up,
         # parity means blowing up in the same entries
@@ -81,7 +82,17 @@ def compare(is_float, method, csr, args, A, B, Ar, Br, converged):
             assert H.scaled_err(A, Ar) <= (1e-3 if converged else 5e-3) and H.scaled_err(B, Br) <= (1e-3 if converged else 5e-3)
             assert obj <= 1e-8
     elif not is_float:
-        assert obj <= (1e-5 if converged else 5e-5)                 # measured: 2.6e-7 converged, 1.3e-5 mid-path
+        # TNCG fp64 end to end, objective within 1e-5 (measured over this suite: 2.6e-7 converged, 1.3e-5 on truncated runs, which end
+        # wherever their last accepted step left them).  Round 6: where the caller hands the problem over, what may exceed 1e-5 is tied to the
+        # REFERENCE's own spread on it -- twice the largest distance among its two k-sum flavours x three orders of the rows' nonzeros
+        # (tests/helpers.py, tncg_yardstick) -- instead of a fixed 5e-5; callers without the problem at hand (golden vectors) keep that.
+        if problem is not None:
+            csc, A0, B0 = problem
+            _, _, _, self_var = H.tncg_yardstick(False, csr, csc, A0, B0, args)
+            print(f"TNCG fp64: objective gpu vs checker {obj:.3g}; the reference's runs among themselves {self_var:.3g}")
+            assert obj <= H.tncg_bound(self_var), (obj, self_var)
+        else:
+            assert obj <= (1e-5 if converged else 5e-5)
     else:
         # fp32 TNCG is chaotic IN THE REFERENCE ITSELF (finite-difference Hessian products in fp32: a 1-ulp perturbation
         # of the starting point moves the compiled reference's final objective by 0.5 % .. 10 %,
@@ -104,7 +115,7 @@ def test_c1_vs_oracle(prec, method, numiter):
     csr, csc, A0, B0 = H.c1_problem(prec)
     A, B, args = gpu_run(csr, csc, A0, B0, method, numiter, 5)
     Ar, Br = oracle_run(prec, csr, csc, A0, B0, method, args)
-    compare(prec, method, csr, args, A, B, Ar, Br, converged=(numiter == "default"))
+    compare(prec, method, csr, args, A, B, Ar, Br, converged=(numiter == "default"), problem=(csc, A0, B0))
 
 
 # ------------------------------------------------------------------ vs golden vectors (compiled reference)
@@ -122,7 +133,7 @@ def test_c1_vs_golden(prec, method, numiter):
     full, csr, csc, A0, B0 = _gold(prec, "c1_")
     A, B, args = gpu_run(csr, csc, A0, B0, method, numiter, 5)
     compare(prec, method, csr, args, A, B, full[f"g4_{method}_{numiter}_A"], full[f"g4_{method}_{numiter}_B"],
-            converged=(numiter == "default"))
+            converged=(numiter == "default"), problem=(csc, A0, B0))
 
 
 @pytest.mark.parametrize("early_stop,reuse_prev", [(True, True), (False, True), (False, False)])
@@ -130,7 +141,7 @@ def test_tncg_toggles_vs_golden(prec, early_stop, reuse_prev):
     full, csr, csc, A0, B0 = _gold(prec, "c1_")
     A, B, args = gpu_run(csr, csc, A0, B0, "tncg", 3, 5, early_stop=early_stop, reuse_prev=reuse_prev)
     tag = f"g4_tncg_es{int(early_stop)}_rp{int(reuse_prev)}_"
-    compare(prec, "tncg", csr, args, A, B, full[tag + "A"], full[tag + "B"], False)
+    compare(prec, "tncg", csr, args, A, B, full[tag + "A"], full[tag + "B"], False, problem=(csc, A0, B0))
 
 
 @pytest.mark.parametrize("method", ["pg", "cg", "tncg"])
@@ -164,7 +175,7 @@ def test_medium_vs_oracle(prec, method, k, numiter):
             assert H.scaled_err(X, X64) <= max(2.0 * H.scaled_err(Xr, X64), 1e-5)
             assert H.scaled_err(X, Xr) <= 1e-4
         return
-    compare(prec, method, csr, args, A, B, Ar, Br, converged=False)
+    compare(prec, method, csr, args, A, B, Ar, Br, converged=False, problem=(csc, A0, B0))
 
 
 def test_pg_maxupd1_single_pass(prec):
