@@ -82,6 +82,36 @@ template <int W> __device__ __forceinline__ float swap_fold(float a, float b)
     }
 }
 
+// The two upper levels of the FLOAT butterfly in place (round 6).  A fold of the transposing butterfly is "lanes of class 0 keep a and add the partner
+// lane's a, lanes of class 1 keep b and add the partner's b"; through update_dpp that is two selects and one DPP add (reg_eval.hpp, fold_pair).  For the
+// levels whose classes are DPP BANKS (lane ^ 8 under row_ror:8: banks {0,1} | {2,3}; lane ^ 7 under row_half_mirror: banks {0,2} | {1,3}) it is two
+// v_add_f32_dpp with complementary bank masks -- as reg_eval.hpp's fold16_banked does with separate, early-clobber outputs, which the lane instances
+// (253-256 VGPRs) have no registers for.  Here the sum lands IN a: the first add rewrites a's class-0 banks from a, the second its class-1 banks from
+// b, and neither reads what the other wrote.  Same operands, same sums, same bits as fold_pair; one instruction per fold less (12 of a batch's 15 folds:
+// 39 of the 512 instructions of the PG headline kernel's pass).  s_nop 1: a DPP source written by the previous VALU instruction needs two wait states,
+// and the hazard recogniser does not look inside inline asm.
+#define PMF_FOLD_IN(CTRL, M0, M1, A, B) \
+    "v_add_f32_dpp " A ", " A ", " A " " CTRL " row_mask:0xf bank_mask:" M0 "\n\t" \
+    "v_add_f32_dpp " A ", " B ", " B " " CTRL " row_mask:0xf bank_mask:" M1 "\n\t"
+__device__ __forceinline__ void fold4_ror8_inplace(float& a0, float& a1, float& a2, float& a3, float b0, float b1, float b2, float b3)
+{
+    asm("s_nop 1\n\t"
+        PMF_FOLD_IN("row_ror:8", "0x3", "0xc", "%0", "%4")
+        PMF_FOLD_IN("row_ror:8", "0x3", "0xc", "%1", "%5")
+        PMF_FOLD_IN("row_ror:8", "0x3", "0xc", "%2", "%6")
+        PMF_FOLD_IN("row_ror:8", "0x3", "0xc", "%3", "%7")
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+__device__ __forceinline__ void fold4_mirror_inplace(float& a0, float& a1, float& a2, float& a3, float b0, float b1, float b2, float b3)
+{
+    asm("s_nop 1\n\t"
+        PMF_FOLD_IN("row_half_mirror", "0x5", "0xa", "%0", "%4")
+        PMF_FOLD_IN("row_half_mirror", "0x5", "0xa", "%1", "%5")
+        PMF_FOLD_IN("row_half_mirror", "0x5", "0xa", "%2", "%6")
+        PMF_FOLD_IN("row_half_mirror", "0x5", "0xa", "%3", "%7")
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+
 // Nothing moves across this line: neither loads at the IR / instruction-selection level (the memory clobber; a bare
 // sched_barrier is no obstacle there, and hipcc then requests a whole pass's LDS reads at once and parks their 200 destination
 // registers -- in practice: the tile -- in AGPRs) nor anything in the machine scheduler.
@@ -792,6 +822,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                                 }
                             });
                         });
+                        if constexpr (sizeof(T) == 4 && N == 16) {                  // lane ^ 8 (row_ror:8), four folds in place
+                            fold4_ror8_inplace(u[0], u[2], u[4], u[6], u[1], u[3], u[5], u[7]);
+                            q[4 * h] = u[0]; q[4 * h + 1] = u[2]; q[4 * h + 2] = u[4]; q[4 * h + 3] = u[6];
+                        } else
                         static_for<0, 4>([&](auto ic) {                             // lane ^ 8 (row_ror:8)
                             constexpr int i = 4 * h + decltype(ic)::value;
                             constexpr int j = 2 * decltype(ic)::value;
@@ -800,6 +834,10 @@ template <class T, int KS, int LV_, int LA_ = 0, int LL_ = 0, int NW_ = 1, bool 
                             else q[i] = (T)0;
                         });
                     });
+                    if constexpr (sizeof(T) == 4 && N8 == 8) {                      // lane ^ 7 (row_half_mirror), four folds in place
+                        fold4_mirror_inplace(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]);
+                        r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+                    } else
                     fold_level<0x141, 4, N8>(c4, q, r);                             // lane ^ 7 (row_half_mirror)
                 }
                 constexpr int N4 = N8 < 4 ? N8 : 4;
